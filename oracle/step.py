@@ -1,0 +1,145 @@
+"""ORACLE — test infrastructure only (see oracle/model.py header). CPU restatement of one
+TD-VC-GAN training iteration: D-step then G-step with both AdamW updates.
+
+Reference anchors: train.py:209-521 (loop body), :259-316 (D-step), :320-510 (G-step),
+:188-189 (AdamW built positionally: eps 1e-8, weight_decay 1e-2 — SURVEY Q11),
+:477-482 (loss assembly). The CREPE-backed F0 term (train.py:429-470) is excluded on both
+sides (torchcrepe absent); F0 enters only as the excitation inputs.
+
+Dead work the reference performs but that reaches no parameter update is not reproduced
+(SURVEY Q3, Q5, Q6): D grads in the G-step, G grads in the D-step. The second, bit-identical
+generator forward of the G-step (Q4) IS recomputed here, as the reference does.
+"""
+from dataclasses import dataclass, field
+
+import torch
+
+from . import losses as L
+from . import model as M
+
+
+@dataclass
+class StepConfig:
+    no_conv: bool = False
+    lambda_rec: float = 0.0
+    lambda_idt: float = 5.0
+    lambda_feat: float = 2.0
+    lambda_spec: float = 5.0
+    lambda_cont_emb: float = 10.0
+    lambda_corrupted: float = 1.0
+    lr_g: float = 1e-4
+    lr_d: float = 1e-4
+    betas: tuple = (0.8, 0.99)
+    eps: float = 1e-8
+    weight_decay: float = 1e-2
+    n_neg: int = 100
+    fft_sizes: tuple = (2048, 1024, 512)
+
+    @staticmethod
+    def from_hparams(train: dict) -> 'StepConfig':
+        g = train.get
+        return StepConfig(no_conv=bool(g('no_conv', False)), lambda_rec=float(g('lambda_rec', 0)),
+                          lambda_idt=float(g('lambda_idt', 0)), lambda_feat=float(g('lambda_feat', 0)),
+                          lambda_spec=float(g('lambda_spec', 0)), lambda_cont_emb=float(g('lambda_cont_emb', 0)),
+                          lambda_corrupted=float(g('lambda_corrupted', 0)), lr_g=float(g('lr_g', 1e-4)),
+                          lr_d=float(g('lr_d', 1e-4)), betas=tuple(g('adam_beta', (0.8, 0.99))))
+
+
+class AdamW:
+    """Decoupled weight decay Adam, torch.optim.AdamW semantics."""
+
+    def __init__(self, params: dict, lr, betas, eps, wd):
+        self.p, self.lr, self.b1, self.b2, self.eps, self.wd = params, lr, betas[0], betas[1], eps, wd
+        self.m = {k: torch.zeros_like(v) for k, v in params.items()}
+        self.v = {k: torch.zeros_like(v) for k, v in params.items()}
+        self.t = {k: 0 for k in params}
+
+    @torch.no_grad()
+    def step(self):
+        for k, p in self.p.items():
+            if p.grad is None:      # skipped entirely, weight decay included
+                continue
+            self.t[k] += 1
+            t = self.t[k]
+            p.mul_(1 - self.lr * self.wd)
+            self.m[k].mul_(self.b1).add_(p.grad, alpha=1 - self.b1)
+            self.v[k].mul_(self.b2).addcmul_(p.grad, p.grad, value=1 - self.b2)
+            denom = (self.v[k].sqrt() / (1 - self.b2 ** t) ** 0.5).add_(self.eps)
+            p.addcdiv_(self.m[k], denom, value=-self.lr / (1 - self.b1 ** t))
+
+    def zero_grad(self):
+        for p in self.p.values():
+            p.grad = None
+
+
+class TrainStep:
+    def __init__(self, sd_g: dict, sd_d: dict, cfg: StepConfig):
+        self.g = {k: v.clone().requires_grad_(True) for k, v in sd_g.items()}
+        self.d = {k: v.clone().requires_grad_(True) for k, v in sd_d.items()}
+        self.cfg = cfg
+        self.opt_g = AdamW(self.g, cfg.lr_g, cfg.betas, cfg.eps, cfg.weight_decay)
+        self.opt_d = AdamW(self.d, cfg.lr_d, cfg.betas, cfg.eps, cfg.weight_decay)
+
+    # -- D-step ---------------------------------------------------------------------
+    def d_losses(self, batch):
+        with torch.no_grad():  # G is not updated by the D-step (Q3)
+            fake, fake_subs, _ = M.generator(self.g, batch['signal_real'], batch['c_tgt'], batch['c_f0_conv'])
+        real_subs = M.disc_subsamples(batch['signal_real'])
+        out_real, _ = M.discriminator(self.d, batch['signal_real'], batch['label_src'], real_subs)
+        out_fake, _ = M.discriminator(self.d, fake, batch['label_tgt'], fake_subs)
+        l_real, l_fake = L.lsgan_to_one(out_real), L.lsgan_to_zero(out_fake)
+        return dict(D_loss_adv_real=l_real, D_loss_adv_fake=l_fake, D_loss=l_real + l_fake)
+
+    # -- G-step ---------------------------------------------------------------------
+    def g_losses(self, batch, idx_x, idx_y):
+        c = self.cfg
+        x = batch['signal_real']
+        fake, fake_subs, emb_real = M.generator(self.g, x, batch['c_tgt'], batch['c_f0_conv'])
+        out_fake, feats_fake = M.discriminator(self.d, fake, batch['label_tgt'], fake_subs)
+        adv = L.lsgan_to_one(out_fake)
+        out = dict(G_loss_adv_fake=adv)
+        total = adv
+        feats_real = None
+        if (c.lambda_rec > 0 or c.lambda_idt > 0) and c.lambda_feat > 0:
+            with torch.no_grad():  # only used detached (Q6)
+                _, feats_real = M.discriminator(self.d, x, batch['label_src'], M.disc_subsamples(x))
+        if c.lambda_idt > 0:
+            if c.no_conv:
+                idt, idt_subs, feats_idt_src = fake, fake_subs, None
+            else:
+                idt, idt_subs, _ = M.generator(self.g, x, batch['c_src'], batch['c_f0_src'])
+            idt_loss = 0
+            if c.lambda_feat > 0:
+                _, feats_idt = M.discriminator(self.d, idt, batch['label_src'], idt_subs)
+                out['G_loss_idt_feat'] = L.feature_matching(feats_idt, feats_real)
+                idt_loss = idt_loss + c.lambda_feat * out['G_loss_idt_feat']
+            if c.lambda_spec > 0:
+                out['G_loss_idt_spec'] = L.log_mel_l1(idt, x, c.fft_sizes)
+                idt_loss = idt_loss + c.lambda_spec * out['G_loss_idt_spec']
+            out['G_loss_idt'] = idt_loss
+            total = total + c.lambda_idt * idt_loss
+        if c.lambda_cont_emb > 0 and c.lambda_corrupted:
+            emb_cor = M.encoder(self.g, batch['signal_corrupted'])
+            out['G_loss_cont_emb'] = L.contrastive(emb_real, emb_cor, idx_x, idx_y)
+            total = total + c.lambda_cont_emb * out['G_loss_cont_emb']
+        out['G_loss'] = total
+        return out
+
+    def run(self, batch, idx_x, idx_y):
+        """One full iteration; returns {name: float} of every logged scalar."""
+        self.opt_d.zero_grad()
+        dl = self.d_losses(batch)
+        dl['D_loss'].backward()
+        self.opt_d.step()
+        self.opt_d.zero_grad()
+        self.opt_g.zero_grad()
+        for p in self.d.values():  # D grads from the G-step are dead work (Q5): not computed
+            p.requires_grad_(False)
+        try:
+            gl = self.g_losses(batch, idx_x, idx_y)
+            gl['G_loss'].backward()
+        finally:
+            for p in self.d.values():
+                p.requires_grad_(True)
+        self.opt_g.step()
+        return {k: float(v) for k, v in {**dl, **gl}.items()}
