@@ -1,0 +1,166 @@
+/* tdvc.h — C ABI of libtdvc_hip.so: MI355X (gfx950) kernels for TD-VC-GAN's G+D train step.
+ *
+ * The reference (vicpc00/td-vc-gan) has NO native/FFI interface: its boundary is the Python
+ * nn.Module surface. This ABI is what sits directly beneath that surface; each
+ * entry point names the ATen operator instance(s) of the reference it replaces (file:line under
+ * /root/reference). INTEGRATION.md shows the ctypes binding a maintainer adds on the reference side.
+ *
+ * Conventions (all entry points):
+ *   - plain C, caller-owned DEVICE pointers, fp32, tensors [B][C][T] with T fastest; a batch stride
+ *     (in elements) is passed wherever a channel-slice of a larger tensor may be used;
+ *   - asynchronous on the hipStream_t passed as void* (NULL = default stream); no allocation, no
+ *     synchronisation, no host read-back inside -> every call is hipGraph-capturable;
+ *   - returns 0 (TDVC_OK) or a negative tdvc_status; never throws. tdvc_last_error() gives text;
+ *   - re-entrant: no mutable globals.
+ */
+#ifndef TDVC_H
+#define TDVC_H
+#include <stddef.h>
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+typedef enum { TDVC_OK = 0, TDVC_EINVAL = -1, TDVC_EWORKSPACE = -2, TDVC_ELAUNCH = -3, TDVC_EUNSUPPORTED = -4 } tdvc_status;
+
+/* Operand transform applied while a tensor is staged into LDS (fused prologue). */
+typedef enum {
+  TDVC_XF_NONE = 0,       /* v */
+  TDVC_XF_LRELU = 1,      /* leaky_relu(v, slope)                      — nn.LeakyReLU before every G conv (model/generator.py:74,82) */
+  TDVC_XF_FILM_LRELU = 2, /* leaky_relu(v*(1+gamma)+beta, slope)       — FiLM (model/generator.py:104-107) fused into posconv's load */
+  TDVC_XF_MASK_LRELU = 3, /* v * (aux>0 ? 1 : slope)                   — backward of an in-place LeakyReLU (model/discriminator.py:20) */
+  TDVC_XF_MASK_TANH = 4   /* v * (1-aux^2)                             — backward of nn.Tanh (model/generator.py:337,347) */
+} tdvc_xform_kind;
+
+typedef struct {
+  int32_t kind;        /* tdvc_xform_kind */
+  float slope;         /* LeakyReLU slope */
+  float scale;         /* multiplies the transformed value (1 = none) */
+  const float* aux;    /* FILM: gamma/beta tensor [B][2C][T]; MASK_*: activation output, same shape as operand */
+  int64_t aux_bs;      /* batch stride of aux (elements) */
+} tdvc_xform;
+
+typedef enum { TDVC_CONV = 0, TDVC_CONV_TRANSPOSE = 1 } tdvc_conv_kind;
+typedef enum { TDVC_POST_NONE = 0, TDVC_POST_LRELU = 1, TDVC_POST_TANH = 2 } tdvc_post_act;
+typedef enum {
+  TDVC_DG_PLAIN = 0,     /* dx = acc */
+  TDVC_DG_MASK_LRELU = 1,/* dx = acc * lrelu'(x_in)                       (pre-activation conv) */
+  TDVC_DG_FILM = 2       /* x_in = h: m = lrelu'(h(1+g)+b); dh2 = acc*m; dx = dh2*(1+g); dgb = [dh2*h ; dh2] */
+} tdvc_dgrad_epilogue;
+
+/* One 1-D convolution layer instance. Replaces aten::conv1d / aten::conv_transpose1d /
+ * aten::convolution_backward for nn.Conv1d / nn.ConvTranspose1d / F.conv1d call sites:
+ * model/generator.py:17-22,75-92,146-157,165-168,214-249,300-362 ; model/discriminator.py:17-37,100-102. */
+typedef struct {
+  int32_t kind;          /* tdvc_conv_kind */
+  int32_t B, Cin, Cout;  /* Cin/Cout are the module's in/out channels (for transpose: x has Cin, y has Cout) */
+  int32_t Tin, Tout;
+  int32_t K, stride, dilation, pad, groups;
+  int32_t reflect;       /* 1: padding_mode='reflect' (stride 1 only), 0: zeros */
+} tdvc_conv_desc;
+
+typedef struct {
+  const float* x; int64_t x_bs;      /* input activation */
+  tdvc_xform x_xf;                   /* prologue on x */
+  const float* w;                    /* effective weight, module layout: conv [Cout][Cin/g][K]; transpose [Cin][Cout/g][K] */
+  const float* bias;                 /* [Cout] or NULL */
+  const float* res; int64_t res_bs;  /* optional residual added before post_act (FiLM block shortcut) */
+  int32_t post_act; float post_slope;
+  float out_scale;                   /* y = out_scale * post(conv+bias+res) + (add ? add : 0) */
+  const float* add; int64_t add_bs;  /* optional running sum (MRF mean, model/generator.py:192-193) */
+  float* y; int64_t y_bs;
+} tdvc_conv_fwd_args;
+
+typedef struct {
+  const float* dy; int64_t dy_bs;    /* upstream gradient w.r.t. y */
+  tdvc_xform dy_xf;                  /* e.g. MASK_LRELU with aux = y for post-activated layers; scale = out_scale */
+  const float* w;
+  int32_t epilogue;                  /* tdvc_dgrad_epilogue */
+  const float* x_in; int64_t x_in_bs; float slope; /* tensor the forward prologue read (mask / FiLM source) */
+  const float* gb; int64_t gb_bs;    /* FiLM gamma/beta (TDVC_DG_FILM) */
+  float* dgb; int64_t dgb_bs;        /* FiLM gradient out [B][2C][T] (TDVC_DG_FILM) */
+  const float* add; int64_t add_bs; float add_scale; /* dx += add_scale*add (residual path gradient) */
+  float* dx; int64_t dx_bs;
+} tdvc_conv_dgrad_args;
+
+typedef struct {
+  const float* x; int64_t x_bs; tdvc_xform x_xf;
+  const float* dy; int64_t dy_bs; tdvc_xform dy_xf;
+  float* dw;        /* accumulated: dw += sum, module layout */
+  float* dbias;     /* accumulated, or NULL */
+  void* workspace; size_t workspace_bytes;
+} tdvc_conv_wgrad_args;
+
+int tdvc_conv_fwd(const tdvc_conv_desc* d, const tdvc_conv_fwd_args* a, void* stream);
+int tdvc_conv_dgrad(const tdvc_conv_desc* d, const tdvc_conv_dgrad_args* a, void* stream);
+int tdvc_conv_wgrad(const tdvc_conv_desc* d, const tdvc_conv_wgrad_args* a, void* stream);
+size_t tdvc_conv_wgrad_workspace(const tdvc_conv_desc* d);
+/* Force the scalar (non-MFMA) kernels: used by tests to cross-check the two code paths. */
+void tdvc_set_force_generic(int on);
+
+/* Multi-tensor weight norm (old-style nn.utils.weight_norm, dim=0; model/generator.py:14,
+ * util/__init__.py:16-20, model/discriminator.py:11): w[row] = g[row] * v[row] / ||v[row]||, one wave per
+ * dim-0 slice, every weight-normed tensor of a model in ONE launch. `params` is the model's flat parameter
+ * arena (v and g live in it), `w` the flat effective-weight arena; the four DEVICE tables give, per row,
+ * the element offsets of v / g in `params`, of w in `w`, and the row length. */
+int tdvc_weight_norm_fwd(const float* params, float* w, const int64_t* row_voff, const int64_t* row_goff,
+                         const int64_t* row_woff, const int32_t* row_len, int nrows, void* stream);
+/* grads[v] (+)= g/||v|| * (dw - v <dw,v>/||v||^2), grads[g] (+)= <dw,v>/||v||; `grads` mirrors `params`. */
+int tdvc_weight_norm_bwd(const float* params, const float* dw, float* grads, const int64_t* row_voff,
+                         const int64_t* row_goff, const int64_t* row_woff, const int32_t* row_len, int nrows,
+                         int accumulate, void* stream);
+
+/* Fused AdamW over a flat parameter arena (torch.optim.AdamW semantics, train.py:188-189:
+ * lr, betas, eps 1e-8, weight_decay 1e-2). The 1-based step count of this update comes from step_dev
+ * (a DEVICE int32, so that a captured hipGraph stays valid across replays) or, if NULL, from `step`. */
+int tdvc_adamw(float* p, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+               float eps, float weight_decay, int step, const int32_t* step_dev, float grad_scale, void* stream);
+int tdvc_inc_i32(int32_t* p, int32_t by, void* stream);
+
+/* Element-wise / reductions over [B][C][T] tensors. */
+int tdvc_l2norm_fwd(const float* x, float* y, float* inv_norm, int B, int C, int T, float eps, void* stream);   /* F.normalize(dim=1), model/generator.py:271 */
+int tdvc_l2norm_bwd(const float* y, const float* inv_norm, const float* dy, float* dx, int B, int C, int T, void* stream);
+int tdvc_gather_ch_fwd(const float* x, const int64_t* label, float* y, int B, int C, int T, void* stream);       /* x.gather(1,label), model/discriminator.py:47-51 */
+int tdvc_gather_ch_bwd(const float* dy, const int64_t* label, float* dx, int B, int C, int T, void* stream);
+int tdvc_concat_cond(const float* emb, const float* exc, float* c, int B, int Ce, int Cx, int T, void* stream);   /* cat([emb.repeat(T), exc]), model/generator.py:387-399 */
+int tdvc_concat_cond_bwd(const float* dc, float* demb, float* dexc, int B, int Ce, int Cx, int T, int accumulate_emb, void* stream);
+int tdvc_axpby(const float* a, const float* b, float* y, float alpha, float beta, int64_t n, void* stream);      /* y = alpha*a + beta*b (b may be NULL) */
+int tdvc_fill(float* y, float value, int64_t n, void* stream);
+
+/* InstanceNorm1d(affine=False, eps) + conditional scale/shift: y = (1+gamma)*IN(x)+beta
+ * (model/conditional_instance_norm.py:4-19). gb is [B][2C][Tg] with Tg = 1 (Linear path) or T (Conv path). */
+int tdvc_cin_fwd(const float* x, const float* gb, float* y, float* mean, float* rstd, int B, int C, int T, int Tg, float eps, void* stream);
+int tdvc_cin_bwd(const float* x, const float* gb, const float* dy, const float* mean, const float* rstd,
+                 float* dx, float* dgb, int B, int C, int T, int Tg, void* stream);
+
+/* Loss reductions. Each writes loss_out[0] (+)= weight*loss and, where present, the gradient
+ * already scaled by weight*upstream. */
+int tdvc_mse_const_fwd(const float* x, int64_t n, float target, float weight, float* loss_out, void* stream);      /* F.mse_loss(x, const), train.py:273-279,329 */
+int tdvc_mse_const_bwd(const float* x, int64_t n, float target, float weight, const float* upstream, float* dx, void* stream);
+int tdvc_l1_fwd(const float* a, const float* b, int64_t n, float weight, float* loss_out, void* stream);          /* F.l1_loss, util/losses.py:63 */
+int tdvc_l1_bwd(const float* a, const float* b, int64_t n, float weight, const float* upstream, float* da, int accumulate, void* stream);
+
+/* log-mel L1 (util/losses.py:28-53 + torchaudio MelSpectrogram semantics). The two GEMMs run on
+ * tdvc_conv_*: STFT = Conv1d(1 -> 2F, K=n_fft, stride=hop) with the windowed DFT basis as weight over the
+ * reflect-padded signal, mel projection = 1x1 Conv1d(F -> n_mels) with the filterbank as weight. These are
+ * the element-wise pieces around them. spec is [B][2F][N] (real rows then imaginary rows). */
+int tdvc_reflect_pad_fwd(const float* x, float* y, int B, int T, int pad, void* stream);       /* torch.stft(center=True, pad_mode='reflect') */
+int tdvc_reflect_pad_bwd(const float* dy, float* dx, int B, int T, int pad, void* stream);
+int tdvc_power_fwd(const float* spec, float* power, int B, int F, int N, void* stream);        /* |.|^2, power=2 */
+int tdvc_power_bwd(const float* spec, const float* dpower, float* dspec, int B, int F, int N, void* stream);
+int tdvc_log_l1_fwd(const float* a, const float* b, int64_t n, float floor_, float weight, float* loss_out, void* stream); /* l1(log(clamp(a)), log(clamp(b))) */
+int tdvc_log_l1_bwd(const float* a, const float* b, int64_t n, float floor_, float weight, const float* upstream, float* da, void* stream);
+
+/* Contrastive InfoNCE (util/losses.py:70-116): cosine logits, softmax, CE against class 0, both
+ * directions, fused with its backward. idx_* [B][T][N] int32 are the negative positions (already skipping
+ * self, util/losses.py:82-83). loss_out[0] += weight*CE; dX, dY += weight * dCE/d{X,Y} (zero them first). */
+int tdvc_contrastive_fwd_bwd(const float* X, const float* Y, const int32_t* idx_x, const int32_t* idx_y, int B, int C, int T, int N,
+                             float weight, float* loss_out, float* dX, float* dY, void* stream);
+
+const char* tdvc_last_error(void);
+int tdvc_version(void);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* TDVC_H */

@@ -1,0 +1,115 @@
+"""ctypes binding of libtdvc_hip.so (the C ABI declared in include/tdvc.h).
+
+The library is loaded on first use and the load FAILS LOUDLY when the shared object is
+missing: there is no CPU / ATen fallback behind these operators. Build it with
+`python -c "import __graft_entry__ as g; g.build()"` or `make -C td-vc-gan_amd/csrc`.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'csrc', 'libtdvc_hip.so')
+
+c_float_p = C.POINTER(C.c_float)
+
+
+class Xform(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('slope', C.c_float), ('scale', C.c_float),
+                ('aux', C.c_void_p), ('aux_bs', C.c_int64)]
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [('kind', C.c_int32), ('B', C.c_int32), ('Cin', C.c_int32), ('Cout', C.c_int32),
+                ('Tin', C.c_int32), ('Tout', C.c_int32), ('K', C.c_int32), ('stride', C.c_int32),
+                ('dilation', C.c_int32), ('pad', C.c_int32), ('groups', C.c_int32), ('reflect', C.c_int32)]
+
+
+class ConvFwdArgs(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('x_bs', C.c_int64), ('x_xf', Xform), ('w', C.c_void_p), ('bias', C.c_void_p),
+                ('res', C.c_void_p), ('res_bs', C.c_int64), ('post_act', C.c_int32), ('post_slope', C.c_float),
+                ('out_scale', C.c_float), ('add', C.c_void_p), ('add_bs', C.c_int64), ('y', C.c_void_p),
+                ('y_bs', C.c_int64)]
+
+
+class ConvDgradArgs(C.Structure):
+    _fields_ = [('dy', C.c_void_p), ('dy_bs', C.c_int64), ('dy_xf', Xform), ('w', C.c_void_p),
+                ('epilogue', C.c_int32), ('x_in', C.c_void_p), ('x_in_bs', C.c_int64), ('slope', C.c_float),
+                ('gb', C.c_void_p), ('gb_bs', C.c_int64), ('dgb', C.c_void_p), ('dgb_bs', C.c_int64),
+                ('add', C.c_void_p), ('add_bs', C.c_int64), ('add_scale', C.c_float),
+                ('dx', C.c_void_p), ('dx_bs', C.c_int64)]
+
+
+class ConvWgradArgs(C.Structure):
+    _fields_ = [('x', C.c_void_p), ('x_bs', C.c_int64), ('x_xf', Xform), ('dy', C.c_void_p), ('dy_bs', C.c_int64),
+                ('dy_xf', Xform), ('dw', C.c_void_p), ('dbias', C.c_void_p), ('workspace', C.c_void_p),
+                ('workspace_bytes', C.c_size_t)]
+
+
+XF_NONE, XF_LRELU, XF_FILM_LRELU, XF_MASK_LRELU, XF_MASK_TANH = range(5)
+CONV, CONV_TRANSPOSE = 0, 1
+POST_NONE, POST_LRELU, POST_TANH = 0, 1, 2
+DG_PLAIN, DG_MASK_LRELU, DG_FILM = 0, 1, 2
+
+# name -> (restype, argtypes); every symbol include/tdvc.h declares
+_vp, _i, _f, _i64 = C.c_void_p, C.c_int, C.c_float, C.c_int64
+SIGNATURES = {
+    'tdvc_conv_fwd': (_i, [C.POINTER(ConvDesc), C.POINTER(ConvFwdArgs), _vp]),
+    'tdvc_conv_dgrad': (_i, [C.POINTER(ConvDesc), C.POINTER(ConvDgradArgs), _vp]),
+    'tdvc_conv_wgrad': (_i, [C.POINTER(ConvDesc), C.POINTER(ConvWgradArgs), _vp]),
+    'tdvc_conv_wgrad_workspace': (C.c_size_t, [C.POINTER(ConvDesc)]),
+    'tdvc_set_force_generic': (None, [_i]),
+    'tdvc_weight_norm_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    'tdvc_weight_norm_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
+    'tdvc_adamw': (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp, _f, _vp]),
+    'tdvc_inc_i32': (_i, [_vp, C.c_int32, _vp]),
+    'tdvc_l2norm_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp]),
+    'tdvc_l2norm_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),
+    'tdvc_gather_ch_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    'tdvc_gather_ch_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    'tdvc_concat_cond': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'tdvc_concat_cond_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'tdvc_axpby': (_i, [_vp, _vp, _vp, _f, _f, _i64, _vp]),
+    'tdvc_fill': (_i, [_vp, _f, _i64, _vp]),
+    'tdvc_cin_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
+    'tdvc_cin_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'tdvc_mse_const_fwd': (_i, [_vp, _i64, _f, _f, _vp, _vp]),
+    'tdvc_mse_const_bwd': (_i, [_vp, _i64, _f, _f, _vp, _vp, _vp]),
+    'tdvc_l1_fwd': (_i, [_vp, _vp, _i64, _f, _vp, _vp]),
+    'tdvc_l1_bwd': (_i, [_vp, _vp, _i64, _f, _vp, _vp, _i, _vp]),
+    'tdvc_reflect_pad_fwd': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'tdvc_reflect_pad_bwd': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'tdvc_power_fwd': (_i, [_vp, _vp, _i, _i, _i, _vp]),
+    'tdvc_power_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
+    'tdvc_log_l1_fwd': (_i, [_vp, _vp, _i64, _f, _f, _vp, _vp]),
+    'tdvc_log_l1_bwd': (_i, [_vp, _vp, _i64, _f, _f, _vp, _vp, _vp]),
+    'tdvc_contrastive_fwd_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
+    'tdvc_last_error': (C.c_char_p, []),
+    'tdvc_version': (_i, []),
+}
+
+_lib = None
+
+
+class TdvcError(RuntimeError):
+    pass
+
+
+def lib():
+    """The loaded library; raises if libtdvc_hip.so has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise TdvcError(f'{LIB_PATH} is missing: build the HIP extension first '
+                            f'(python -c "import __graft_entry__ as g; g.build()"). '
+                            'There is no CPU fallback for this path.')
+        l = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(l, name)      # AttributeError if the .so does not export a declared symbol
+            fn.restype, fn.argtypes = res, args
+        _lib = l
+    return _lib
+
+
+def check(rc):
+    if rc != 0:
+        raise TdvcError(f'tdvc call failed ({rc}): {lib().tdvc_last_error().decode()}')

@@ -1,0 +1,160 @@
+"""Flat HBM arenas for one model: parameters, gradients, effective (weight-normed) weights.
+
+MI355X-first memory layout: every parameter of a model is a view into ONE
+contiguous fp32 buffer `P`; gradients mirror it in `G`; the effective weights w = g*v/||v|| of all
+weight-normed convs live in `W` (rebuilt by one multi-tensor kernel per optimizer step) and their
+gradients accumulate in `dW`. Consequences: AdamW is a single kernel over the live prefix of `P`,
+gradient all-reduce is a handful of large RCCL calls over `G`, and zero_grad is two memsets.
+
+Parameters the forward never reads (`decoder.excite_downsample.0.*`) sit at the tail of
+the arena, outside the live prefix: their .grad stays None and AdamW skips them, exactly like
+torch.optim.AdamW skips grad-less parameters in the reference (train.py:188, Q7).
+"""
+import torch
+
+from . import _lib as L
+
+
+class ConvSlot:
+    """Raw device addresses of one conv layer's tensors inside the arenas."""
+    __slots__ = ('w', 'b', 'dw', 'db', 'trainable', 'arena')
+
+    def __init__(self, w=0, b=0, dw=0, db=0, trainable=True, arena=None):
+        self.w, self.b, self.dw, self.db, self.trainable, self.arena = w, b, dw, db, trainable, arena
+
+
+class ParamArena:
+    def __init__(self, module: torch.nn.Module, device, dead_prefixes=()):
+        named = list(module.named_parameters())
+        live = [(k, p) for k, p in named if not any(k.startswith(d) for d in dead_prefixes)]
+        dead = [(k, p) for k, p in named if any(k.startswith(d) for d in dead_prefixes)]
+        self.device = torch.device(device)
+        self.offsets = {}
+        off = 0
+        for k, p in live + dead:
+            self.offsets[k] = off
+            off += (p.numel() + 3) // 4 * 4          # keep every tensor 16-byte aligned
+            if k == live[-1][0]:
+                self.n_live = off
+        self.n_total = off
+        self.P = torch.zeros(self.n_total, dtype=torch.float32, device=self.device)
+        self.G = torch.zeros(self.n_total, dtype=torch.float32, device=self.device)
+        self.params = {}
+        self.live_keys = [k for k, _ in live]
+        with torch.no_grad():
+            for k, p in live + dead:
+                o = self.offsets[k]
+                view = self.P[o:o + p.numel()].view(p.shape)
+                view.copy_(p.data.to(self.device, torch.float32))
+                p.data = view
+                p.grad = None
+                self.params[k] = p
+        # effective-weight arena for weight-normed tensors
+        self.wn = []          # (prefix, v_off, g_off, w_off, rows, cols)
+        woff = 0
+        for k, p in live:
+            if k.endswith('.weight_v'):
+                pre = k[:-len('.weight_v')]
+                rows, cols = p.shape[0], p.numel() // p.shape[0]
+                self.wn.append((pre, self.offsets[k], self.offsets[pre + '.weight_g'], woff, rows, cols))
+                woff += (p.numel() + 3) // 4 * 4
+        self.n_w = max(woff, 4)
+        self.W = torch.zeros(self.n_w, dtype=torch.float32, device=self.device)
+        self.dW = torch.zeros(self.n_w, dtype=torch.float32, device=self.device)
+        self.w_offsets = {pre: wo for pre, _, _, wo, _, _ in self.wn}
+        if self.wn:
+            rv, rg, rw, rl = [], [], [], []
+            for _, vo, go, wo, rows, cols in self.wn:
+                for r in range(rows):
+                    rv.append(vo + r * cols); rg.append(go + r); rw.append(wo + r * cols); rl.append(cols)
+            t = lambda a, dt: torch.tensor(a, dtype=dt, device=self.device)
+            self.row_voff, self.row_goff, self.row_woff = t(rv, torch.int64), t(rg, torch.int64), t(rw, torch.int64)
+            self.row_len = t(rl, torch.int32)
+            self.nrows = len(rl)
+        else:
+            self.nrows = 0
+        self.wgrad_enabled = True
+        self.token = torch.zeros(1, dtype=torch.float32, device=self.device, requires_grad=True)
+        self._grads_attached = False
+        self._finish_queued = False
+
+    # ------------------------------------------------------------------ addresses
+    def slot(self, prefix: str, has_bias: bool) -> ConvSlot:
+        """Addresses for the conv whose parameters are `prefix`.{weight_v,weight_g | weight}[, bias]."""
+        pb, gb = self.P.data_ptr(), self.G.data_ptr()
+        if prefix in self.w_offsets:
+            wo = self.w_offsets[prefix]
+            w, dw = self.W.data_ptr() + 4 * wo, self.dW.data_ptr() + 4 * wo
+        else:
+            o = self.offsets[prefix + '.weight']
+            w, dw = pb + 4 * o, gb + 4 * o
+        b = db = 0
+        if has_bias:
+            o = self.offsets[prefix + '.bias']
+            b, db = pb + 4 * o, gb + 4 * o
+        return ConvSlot(w, b, dw, db, True, self)
+
+    def owns(self, p: torch.Tensor) -> bool:
+        a = p.data_ptr()
+        return self.P.data_ptr() <= a < self.P.data_ptr() + 4 * self.n_total
+
+    # ------------------------------------------------------------------ per-step kernels
+    def materialize(self):
+        """w = g * v / ||v|| for every weight-normed tensor: one launch."""
+        if self.nrows:
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            L.check(L.lib().tdvc_weight_norm_fwd(self.P.data_ptr(), self.W.data_ptr(), self.row_voff.data_ptr(),
+                                                 self.row_goff.data_ptr(), self.row_woff.data_ptr(),
+                                                 self.row_len.data_ptr(), self.nrows, st))
+
+    def zero_grad(self):
+        self.G.zero_()
+        self.dW.zero_()
+        for p in self.params.values():
+            p.grad = None
+        self._grads_attached = False
+
+    def finish_grads(self):
+        """Fold the effective-weight gradients into (v, g) gradients and expose .grad views."""
+        self._finish_queued = False
+        if self.nrows:
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            L.check(L.lib().tdvc_weight_norm_bwd(self.P.data_ptr(), self.dW.data_ptr(), self.G.data_ptr(),
+                                                 self.row_voff.data_ptr(), self.row_goff.data_ptr(),
+                                                 self.row_woff.data_ptr(), self.row_len.data_ptr(), self.nrows, 0, st))
+        if not self._grads_attached:
+            for k in self.live_keys:
+                p = self.params[k]
+                o = self.offsets[k]
+                p.grad = self.G[o:o + p.numel()].view(p.shape)
+            self._grads_attached = True
+
+    def queue_finish(self):
+        """Called from inside a backward: run finish_grads once, when this backward pass ends."""
+        if not self._finish_queued:
+            self._finish_queued = True
+            torch.autograd.Variable._execution_engine.queue_callback(self.finish_grads)
+
+
+class FlatAdamW:
+    """torch.optim.AdamW semantics (decoupled decay, bias correction, eps outside the sqrt) as one
+    kernel over the arena's live prefix. The step counter lives on the device so that a captured
+    hipGraph of the whole iteration replays correctly."""
+
+    def __init__(self, arena: ParamArena, lr=1e-4, betas=(0.8, 0.99), eps=1e-8, weight_decay=1e-2):
+        self.a, self.lr, self.betas, self.eps, self.wd = arena, lr, betas, eps, weight_decay
+        self.m = torch.zeros(arena.n_live, dtype=torch.float32, device=arena.device)
+        self.v = torch.zeros(arena.n_live, dtype=torch.float32, device=arena.device)
+        self.step_dev = torch.zeros(1, dtype=torch.int32, device=arena.device)
+
+    def step(self, grad_scale=1.0):
+        a = self.a
+        st = torch.cuda.current_stream(a.device).cuda_stream
+        lib = L.lib()
+        L.check(lib.tdvc_inc_i32(self.step_dev.data_ptr(), 1, st))
+        L.check(lib.tdvc_adamw(a.P.data_ptr(), a.G.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), a.n_live,
+                               self.lr, self.betas[0], self.betas[1], self.eps, self.wd, 0, self.step_dev.data_ptr(),
+                               grad_scale, st))
+
+    def zero_grad(self):
+        self.a.zero_grad()

@@ -1,0 +1,571 @@
+// MFMA implicit-GEMM kernels for the reduced stride-1 conv problem (see conv_common.h).
+// gfx950 only: v_mfma_f32_16x16x4_f32 (exact fp32, 64 FLOP/clk/SIMD), 64-wide waves,
+// LDS-staged input tile + weight tile, fused prologue (activation / FiLM) on load and fused
+// epilogue (bias, residual, activation, MRF running mean, activation-grad masks, FiLM grads).
+#include "conv_common.h"
+
+namespace tdvc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// ----------------------------------------------------------------------------------------------
+// element-wise epilogue shared by the MFMA and the scalar kernels
+__device__ __forceinline__ void conv_epilogue(const GemmConvP& p, float acc, int b, int ch, int u, int Ctot) {
+  const long oi = (long)ch * p.Ty + u;
+  float v = acc;
+  if (p.epi == EPI_FWD) {
+    if (p.bias) v += p.bias[ch];
+    if (p.res) v += p.res[(long)b * p.res_bs + oi];
+    if (p.post == POST_LRELU) v = lrelu_f(v, p.post_slope);
+    else if (p.post == POST_TANH) v = tanhf(v);
+    v *= p.out_scale;
+  } else if (p.epi == EPI_MASK) {
+    float m = p.mx[(long)b * p.mx_bs + oi];
+    v = m > 0.f ? v : v * p.m_slope;
+  } else if (p.epi == EPI_FILM) {
+    const float h = p.mx[(long)b * p.mx_bs + oi];
+    const float* gp = p.gb + (long)b * p.gb_bs + oi;
+    const float ga = gp[0], be = gp[(long)Ctot * p.Ty];
+    const float h2 = h * (1.f + ga) + be;
+    const float dh2 = h2 > 0.f ? v : v * p.m_slope;
+    float* dg = p.dgb + (long)b * p.dgb_bs + oi;
+    dg[0] = dh2 * h;
+    dg[(long)Ctot * p.Ty] = dh2;
+    v = dh2 * (1.f + ga);
+  }
+  if (p.add) v += p.add_scale * p.add[(long)b * p.add_bs + oi];
+  p.y[(long)b * p.y_bs + oi] = v;
+}
+
+// A-matrix element for reduced row `row`, reduced channel `cr`, reduced tap `j` of group g.
+template <int MODE>
+__device__ __forceinline__ float weight_elem(const GemmConvP& p, int g, int row, int cr, int j) {
+  if (row >= p.R || cr >= p.Cred) return 0.f;
+  int m = row, c = cr, k;
+  if (MODE == MODE_DIRECT) {
+    k = p.tap_flip ? p.K - 1 - j : j;
+  } else if (MODE == MODE_DOWN) {
+    c = cr / p.s; int phi = cr - c * p.s;
+    k = phi + j * p.s;
+  } else {
+    m = row / p.s; int phi = row - m * p.s;
+    k = phi + (p.J - 1 - j) * p.s;
+  }
+  if (k >= p.K) return 0.f;
+  return p.w[(long)g * p.w_sg + (long)m * p.w_sm + (long)c * p.w_sc + k];
+}
+
+// ----------------------------------------------------------------------------------------------
+// Block tile: MT = 16*M_REP*WM rows x NT = 16*N_REP*WN columns, 4 waves arranged WM x WN.
+template <int MODE, int M_REP, int N_REP, int WM, int WN>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmConvP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int MT = 16 * M_REP * WM;
+  constexpr int NT = 16 * N_REP * WN;
+  static_assert(WM * WN == 4, "4 waves per block");
+  float* xs = smem;                    // [Cc][XS]
+  float* ws = smem + p.Cc * p.XS;      // [MT][WS], ws[m][j*Cc + c]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int ln = lane & 15, kq = lane >> 4;
+  const int n0 = blockIdx.x * NT;
+  const int mtiles = (p.R + MT - 1) / MT;
+  const int mt = blockIdx.y % mtiles, g = blockIdx.y / mtiles;
+  const int b = blockIdx.z;
+  const int r0 = mt * MT;
+  const int Cx_tot = p.groups * p.x.Cg;
+  const int i0 = (MODE == MODE_DIRECT) ? (-p.pad - p.lo) : 0;   // staged index of tap 0 for column n0
+
+  f32x4 acc[M_REP][N_REP];
+#pragma unroll
+  for (int m = 0; m < M_REP; ++m)
+#pragma unroll
+    for (int n = 0; n < N_REP; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int wcol0 = wn * 16 * N_REP;   // wave's first column inside the block tile
+  const int wrow0 = wm * 16 * M_REP;
+
+  // reflect-fold bookkeeping (dgrad of a reflect-padded stride-1 conv): a column u also collects
+  // the padded positions -u (1<=u<=mp) and 2(T-1)-u (T-1-mp<=u<=T-2).
+  bool needL = false, needR = false;
+  if (MODE == MODE_DIRECT && p.mirror_pad > 0) {
+    const int c_lo = n0 + wcol0, c_hi = c_lo + 16 * N_REP - 1;
+    needL = (c_lo <= p.mirror_pad) && (c_hi >= 1);
+    needR = (c_lo <= p.N - 2) && (c_hi >= p.N - 1 - p.mirror_pad);
+  }
+
+  for (int c0 = 0; c0 < p.Cred; c0 += p.Cc) {
+    __syncthreads();
+    // ---- stage X' chunk
+    if (MODE == MODE_DOWN && p.stage_rows) {
+      // large stride (STFT framing): consecutive reduced rows (c,phi) are consecutive samples in HBM,
+      // so lanes run along rows; XS is odd-ish (17 mod 32) so the LDS writes stay conflict-free
+      const int tot = p.Cc * p.span;
+      const float inv_cc = 1.0f / (float)p.Cc;
+      for (int e = tid; e < tot; e += 256) {
+        const int i = (int)(((float)e + 0.5f) * inv_cc);
+        const int r = e - i * p.Cc;
+        const int cr = c0 + r;
+        float v = 0.f;
+        if (cr < p.Cred) {
+          const int c = cr / p.s, phi = cr - c * p.s;
+          v = fetch_opnd(p.x, b, g * p.x.Cg + c, (n0 + p.lo + i) * p.s + phi - p.pad, p.reflect, Cx_tot);
+        }
+        xs[r * p.XS + i] = v;
+      }
+    } else {
+      for (int r = wave; r < p.Cc; r += 4) {
+        const int cr = c0 + r;
+        const bool rv = cr < p.Cred;
+        int ch, phi = 0;
+        if (MODE == MODE_DOWN) { int c = cr / p.s; phi = cr - c * p.s; ch = g * p.x.Cg + c; }
+        else ch = g * p.x.Cg + cr;
+        float* row = xs + r * p.XS;
+        for (int i = lane; i < p.span; i += 64) {
+          const int xi = n0 + p.lo + i;
+          const int q = (MODE == MODE_DOWN) ? xi * p.s + phi - p.pad : xi;
+          row[i] = rv ? fetch_opnd(p.x, b, ch, q, p.reflect, Cx_tot) : 0.f;
+        }
+      }
+    }
+    // ---- stage A chunk
+    const int jc = p.J * p.Cc;
+    const float inv_cc = 1.0f / (float)p.Cc;
+    for (int m = wave; m < MT; m += 4) {
+      float* row = ws + m * p.WS;
+      for (int idx = lane; idx < jc; idx += 64) {
+        const int j = (int)(((float)idx + 0.5f) * inv_cc);
+        const int c = idx - j * p.Cc;
+        row[idx] = weight_elem<MODE>(p, g, r0 + m, c0 + c, j);
+      }
+    }
+    __syncthreads();
+
+    // ---- MFMA main loop: K dimension = (tap j, channel c) with c innermost
+    const int csteps = p.Cc >> 2;
+    const float* a_base = ws + (wrow0 + ln) * p.WS + kq;
+    const float* b_base = xs + kq * p.XS + wcol0 + ln + i0;
+    for (int j = 0; j < p.J; ++j) {
+      const float* aj = a_base + j * p.Cc;
+      const float* bj = b_base + j * p.d;
+      for (int cs = 0; cs < csteps; ++cs) {
+        float a[M_REP], bv[N_REP];
+#pragma unroll
+        for (int m = 0; m < M_REP; ++m) a[m] = aj[m * 16 * p.WS + cs * 4];
+#pragma unroll
+        for (int n = 0; n < N_REP; ++n) bv[n] = bj[cs * 4 * p.XS + n * 16];
+#pragma unroll
+        for (int m = 0; m < M_REP; ++m)
+#pragma unroll
+          for (int n = 0; n < N_REP; ++n)
+            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv[n], acc[m][n], 0, 0, 0);
+      }
+    }
+
+    if (MODE == MODE_DIRECT && (needL || needR)) {
+      for (int side = 0; side < 2; ++side) {
+        if (side == 0 ? !needL : !needR) continue;
+        int mb[N_REP]; bool mv[N_REP];
+#pragma unroll
+        for (int n = 0; n < N_REP; ++n) {
+          const int u = n0 + wcol0 + n * 16 + ln;
+          if (side == 0) { mv[n] = (u >= 1 && u <= p.mirror_pad && u < p.N); mb[n] = -u - n0 + p.mirror_pad; }
+          else { mv[n] = (u >= p.N - 1 - p.mirror_pad && u <= p.N - 2 && u >= 0); mb[n] = 2 * (p.N - 1) - u - n0 + p.mirror_pad; }
+        }
+        for (int j = 0; j < p.J; ++j) {
+          const float* aj = a_base + j * p.Cc;
+          for (int cs = 0; cs < csteps; ++cs) {
+            float a[M_REP], bv[N_REP];
+#pragma unroll
+            for (int m = 0; m < M_REP; ++m) a[m] = aj[m * 16 * p.WS + cs * 4];
+#pragma unroll
+            for (int n = 0; n < N_REP; ++n) {
+              const int idx = mb[n] + j * p.d;
+              const bool ok = mv[n] && idx >= 0 && idx < p.span;
+              const float t = xs[(cs * 4 + kq) * p.XS + (ok ? idx : 0)];
+              bv[n] = ok ? t : 0.f;
+            }
+#pragma unroll
+            for (int m = 0; m < M_REP; ++m)
+#pragma unroll
+              for (int n = 0; n < N_REP; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv[n], acc[m][n], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + reg
+  const int Cy_tot = p.groups * p.Cy_g;
+#pragma unroll
+  for (int m = 0; m < M_REP; ++m) {
+#pragma unroll
+    for (int n = 0; n < N_REP; ++n) {
+      const int col = n0 + wcol0 + n * 16 + ln;
+      if (col >= p.N) continue;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0 + wrow0 + m * 16 + kq * 4 + r;
+        if (row >= p.R) continue;
+        int ch, u;
+        if (MODE == MODE_UP) {
+          const int mm = row / p.s, phi = row - mm * p.s;
+          ch = g * p.Cy_g + mm; u = col * p.s + phi - p.pad;
+          if (u < 0 || u >= p.Ty) continue;
+        } else { ch = g * p.Cy_g + row; u = col; }
+        conv_epilogue(p, acc[m][n][r], b, ch, u, Cy_tot);
+      }
+    }
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Scalar kernel for the same reduced problem: one thread per output element. Used for shapes the
+// MFMA tiling does not cover (Cred % 4 != 0, i.e. 1-channel inputs and depthwise FIR filters) and
+// as an independent cross-check of the MFMA path in tests.
+template <int MODE>
+__global__ __launch_bounds__(256) void conv_scalar_kernel(const GemmConvP p) {
+  const long total = (long)p.N * p.R;
+  const int g = blockIdx.y, b = blockIdx.z;
+  const int Cx_tot = p.groups * p.x.Cg, Cy_tot = p.groups * p.Cy_g;
+  for (long e = (long)blockIdx.x * 256 + threadIdx.x; e < total; e += (long)gridDim.x * 256) {
+    const int row = (int)(e / p.N), col = (int)(e - (long)row * p.N);
+    float acc = 0.f;
+    for (int cr = 0; cr < p.Cred; ++cr) {
+      int ch, phi = 0;
+      if (MODE == MODE_DOWN) { int c = cr / p.s; phi = cr - c * p.s; ch = g * p.x.Cg + c; }
+      else ch = g * p.x.Cg + cr;
+      for (int j = 0; j < p.J; ++j) {
+        const float wv = weight_elem<MODE>(p, g, row, cr, j);
+        int xi;
+        if (MODE == MODE_DIRECT) xi = col + j * p.d - p.pad;
+        else if (MODE == MODE_DOWN) xi = col + j;
+        else xi = col - (p.J - 1) + j;
+        const int q = (MODE == MODE_DOWN) ? xi * p.s + phi - p.pad : xi;
+        float xv = fetch_opnd(p.x, b, ch, q, p.reflect, Cx_tot);
+        if (MODE == MODE_DIRECT && p.mirror_pad > 0) {
+          // fold: padded positions -col and 2(T-1)-col also map onto this column
+          if (col >= 1 && col <= p.mirror_pad) xv += fetch_opnd(p.x, b, ch, -col + j * p.d - p.pad, 0, Cx_tot);
+          if (col >= p.N - 1 - p.mirror_pad && col <= p.N - 2)
+            xv += fetch_opnd(p.x, b, ch, 2 * (p.N - 1) - col + j * p.d - p.pad, 0, Cx_tot);
+        }
+        acc += wv * xv;
+      }
+    }
+    int ch, u;
+    if (MODE == MODE_UP) {
+      const int mm = row / p.s, phi = row - mm * p.s;
+      ch = g * p.Cy_g + mm; u = col * p.s + phi - p.pad;
+      if (u < 0 || u >= p.Ty) continue;
+    } else { ch = g * p.Cy_g + row; u = col; }
+    conv_epilogue(p, acc, b, ch, u, Cy_tot);
+  }
+}
+
+// ----------------------------------------------------------------------------------------------
+// Weight-gradient: dW[r][c][j] = sum_{b,n} A'[r][n] * X'[c][n + j*d + lo]. One block = one
+// (row tile, 16-channel tile) x (time chunk, batch group); the 4 waves split the time chunk and
+// are summed through LDS; the block writes its partial into a slab (no atomics: deterministic).
+template <int MODE, int M_REP, int J>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p, int bpb, int B) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int MT = 16 * M_REP;
+  constexpr int E = M_REP * J * 4;
+  float* as = smem;                 // [MT][AS]
+  float* xs = smem + MT * p.AS;     // [16][XS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ln = lane & 15, kq = lane >> 4;
+  const int mtiles = (p.R + MT - 1) / MT, ctiles = (p.Cred + 15) / 16;
+  int yy = blockIdx.y;
+  const int ct = yy % ctiles; yy /= ctiles;
+  const int mt = yy % mtiles; const int g = yy / mtiles;
+  const int bg = blockIdx.x / p.ntiles, tile = blockIdx.x % p.ntiles;
+  const int nc0 = tile * p.NTc;
+  const int r0 = mt * MT, c0 = ct * 16;
+  const int Ca_tot = p.groups * p.a.Cg, Cx_tot = p.groups * p.x.Cg;
+  const int i0 = (MODE == MODE_DIRECT) ? (-p.pad - p.lo) : 0;
+
+  f32x4 acc[M_REP][J];
+#pragma unroll
+  for (int m = 0; m < M_REP; ++m)
+#pragma unroll
+    for (int j = 0; j < J; ++j) acc[m][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int b_lo = bg * bpb, b_hi = min(B, b_lo + bpb);
+  for (int b = b_lo; b < b_hi; ++b) {
+    __syncthreads();
+    for (int m = wave; m < MT; m += 4) {
+      const int row = r0 + m;
+      const int ch = g * p.a.Cg + row;
+      float* dst = as + m * p.AS;
+      for (int i = lane; i < p.NTc; i += 64) {
+        const int n = nc0 + i;
+        dst[i] = (row < p.R && n < p.N) ? fetch_opnd(p.a, b, ch, n, 0, Ca_tot) : 0.f;
+      }
+    }
+    for (int r = wave; r < 16; r += 4) {
+      const int cr = c0 + r;
+      const bool rv = cr < p.Cred;
+      int ch, phi = 0;
+      if (MODE == MODE_DOWN) { int c = cr / p.s; phi = cr - c * p.s; ch = g * p.x.Cg + c; }
+      else ch = g * p.x.Cg + cr;
+      float* dst = xs + r * p.XS;
+      for (int i = lane; i < p.span; i += 64) {
+        const int xi = nc0 + p.lo + i;
+        const int q = (MODE == MODE_DOWN) ? xi * p.s + phi - p.pad : xi;
+        dst[i] = rv ? fetch_opnd(p.x, b, ch, q, p.reflect, Cx_tot) : 0.f;
+      }
+    }
+    __syncthreads();
+
+    const int per_wave = p.NTc >> 2;
+    const float* a_base = as + ln * p.AS + kq;
+    const float* b_base = xs + ln * p.XS + kq + i0;
+    for (int nn = wave * per_wave; nn < (wave + 1) * per_wave; nn += 4) {
+      float a[M_REP];
+#pragma unroll
+      for (int m = 0; m < M_REP; ++m) a[m] = a_base[m * 16 * p.AS + nn];
+#pragma unroll
+      for (int j = 0; j < J; ++j) {
+        const float bv = b_base[nn + j * p.d];
+#pragma unroll
+        for (int m = 0; m < M_REP; ++m)
+          acc[m][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv, acc[m][j], 0, 0, 0);
+      }
+    }
+  }
+
+  // ---- cross-wave sum through LDS, one wave at a time (bounds the buffer to E*64 floats)
+  float* red = smem;
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int m = 0; m < M_REP; ++m)
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int e = (m * J + j) * 4 + r;
+            if (w == 0) red[e * 64 + lane] = acc[m][j][r];
+            else red[e * 64 + lane] += acc[m][j][r];
+          }
+    }
+  }
+  __syncthreads();
+  float* slab = p.slab + (long)blockIdx.x * p.slab_stride;
+  for (int idx = tid; idx < E * 64; idx += 256) {
+    const int e = idx >> 6, l = idx & 63;
+    const int r = e & 3, mj = e >> 2;
+    const int j = mj % J, m = mj / J;
+    const int row = r0 + m * 16 + (l >> 4) * 4 + r;
+    const int cr = c0 + (l & 15);
+    if (row >= p.R || cr >= p.Cred) continue;
+    int c = cr, k = j;
+    if (MODE == MODE_DOWN) { c = cr / p.s; k = (cr - c * p.s) + j * p.s; if (k >= p.K) continue; }
+    slab[(long)g * p.w_sg + (long)row * p.w_sm + (long)c * p.w_sc + k] = red[idx];
+  }
+}
+
+// Row sums of the transformed dy operand -> bias gradient. One block per (channel, sample).
+__global__ __launch_bounds__(256) void conv_bias_grad_kernel(const Opnd a, int N, int Ctot, float* dbias) {
+  const int ch = blockIdx.x, b = blockIdx.y;
+  float s = 0.f;
+  for (int n = threadIdx.x; n < N; n += 256) s += fetch_opnd(a, b, ch, n, 0, Ctot);
+  __shared__ float sh[4];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(&dbias[ch], sh[0] + sh[1] + sh[2] + sh[3]);
+}
+
+// dw[i] += sum_s slab[s][i]
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, int nslab, long stride, long n, float* dw) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    float s = 0.f;
+    for (int k = 0; k < nslab; ++k) s += slab[(long)k * stride + i];
+    dw[i] += s;
+  }
+}
+
+// Scalar weight-gradient: one block per weight element, reduction over (b, n).
+template <int MODE>
+__global__ __launch_bounds__(256) void conv_wgrad_scalar_kernel(const WgradP p, int B, float* dw) {
+  // blockIdx.x enumerates (g, row, c, k) of the module weight
+  const int Cw = p.x.Cg;            // channels per group in the module weight's 2nd dim
+  long e = blockIdx.x;
+  const int k = (int)(e % p.K); e /= p.K;
+  const int c = (int)(e % Cw); e /= Cw;
+  const int row = (int)(e % p.R); const int g = (int)(e / p.R);
+  const int Ca_tot = p.groups * p.a.Cg, Cx_tot = p.groups * p.x.Cg;
+  float s = 0.f;
+  for (int b = 0; b < B; ++b) {
+    for (int n = threadIdx.x; n < p.N; n += 256) {
+      const float av = fetch_opnd(p.a, b, g * p.a.Cg + row, n, 0, Ca_tot);
+      const int q = (MODE == MODE_DOWN) ? n * p.s + k - p.pad : n + k * p.d - p.pad;
+      s += av * fetch_opnd(p.x, b, g * p.x.Cg + c, q, p.reflect, Cx_tot);
+    }
+  }
+  __shared__ float sh[4];
+  for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) dw[(long)g * p.w_sg + (long)row * p.w_sm + (long)c * p.w_sc + k] += sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+}  // namespace tdvc
+
+// ================================================================================================
+// host-side launchers (called from conv_api.cpp)
+namespace tdvc {
+
+template <typename KernelT>
+static inline void allow_big_lds(KernelT k) {
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+template <int MODE, int M_REP, int N_REP, int WM, int WN>
+static hipError_t launch_gemm_cfg(const GemmConvP& p, int B, hipStream_t st) {
+  constexpr int MT = 16 * M_REP * WM, NT = 16 * N_REP * WN;
+  auto k = conv_gemm_kernel<MODE, M_REP, N_REP, WM, WN>;
+  static bool once = false;
+  if (!once) { allow_big_lds(k); once = true; }
+  dim3 grid((p.N + NT - 1) / NT, p.groups * ((p.R + MT - 1) / MT), B);
+  size_t lds = (size_t)(p.Cc * p.XS + MT * p.WS) * sizeof(float);
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
+  return hipGetLastError();
+}
+
+// Tile shape selection; fills the LDS geometry (Cc, span, XS, WS) for the chosen NT/MT.
+template <int MODE>
+hipError_t launch_conv_gemm(GemmConvP p, int B, hipStream_t st) {
+  int MT, NT, cfg;
+  if (p.N <= 80) { if (p.R <= 16) { cfg = 3; MT = 16; NT = 64; } else { cfg = 4; MT = 64; NT = 64; } }
+  else if (p.R <= 16) { cfg = 0; MT = 16; NT = 256; }
+  else if (p.R <= 32) { cfg = 1; MT = 32; NT = 256; }
+  else { cfg = 2; MT = 64; NT = 256; }
+  const int hi = (MODE == MODE_DIRECT) ? (p.J - 1) * p.d - p.pad + p.mirror_pad : (MODE == MODE_DOWN ? p.J - 1 : 0);
+  p.lo = (MODE == MODE_DIRECT) ? -p.pad - p.mirror_pad : (MODE == MODE_DOWN ? 0 : -(p.J - 1));
+  p.span = NT + hi - p.lo;
+  p.XS = ((p.span + 31) / 32) * 32 + 16;   // == 16 (mod 32): the two k-rows of a 32-lane group hit disjoint banks
+  // channel chunk: multiple of 4, sized so that LDS stays <= ~60 KB (>= 2 blocks per CU)
+  const int unit = 4;
+  p.stage_rows = (MODE == MODE_DOWN && p.s >= 16) ? 1 : 0;
+  if (p.stage_rows) p.XS += 1;             // 17 (mod 32): row-major lane order writes conflict-free, reads 1 extra cycle
+  int Cc = unit;
+  while (true) {
+    int next = Cc + unit;
+    if (next > 32 || next > ((p.Cred + unit - 1) / unit) * unit) break;
+    size_t lds = (size_t)(next * p.XS + MT * (p.J * next + 2)) * 4;
+    if (lds > 60 * 1024) break;
+    Cc = next;
+  }
+  p.Cc = Cc;
+  p.WS = p.J * Cc + 2;                      // WS/2 odd: 16 rows x 2 k-lanes hit 32 distinct banks
+  switch (cfg) {
+    case 0: return launch_gemm_cfg<MODE, 1, 4, 1, 4>(p, B, st);
+    case 1: return launch_gemm_cfg<MODE, 2, 4, 1, 4>(p, B, st);
+    case 2: return launch_gemm_cfg<MODE, 4, 4, 1, 4>(p, B, st);
+    case 3: return launch_gemm_cfg<MODE, 1, 1, 1, 4>(p, B, st);
+    default: return launch_gemm_cfg<MODE, 1, 4, 4, 1>(p, B, st);
+  }
+}
+
+template <int MODE>
+hipError_t launch_conv_scalar(GemmConvP p, int B, hipStream_t st) {
+  p.lo = 0; p.span = 0;
+  long total = (long)p.N * p.R;
+  int gx = (int)((total + 255) / 256); if (gx > 4096) gx = 4096; if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(conv_scalar_kernel<MODE>, dim3(gx, p.groups, B), dim3(256), 0, st, p);
+  return hipGetLastError();
+}
+
+template hipError_t launch_conv_gemm<MODE_DIRECT>(GemmConvP, int, hipStream_t);
+template hipError_t launch_conv_gemm<MODE_DOWN>(GemmConvP, int, hipStream_t);
+template hipError_t launch_conv_gemm<MODE_UP>(GemmConvP, int, hipStream_t);
+template hipError_t launch_conv_scalar<MODE_DIRECT>(GemmConvP, int, hipStream_t);
+template hipError_t launch_conv_scalar<MODE_DOWN>(GemmConvP, int, hipStream_t);
+template hipError_t launch_conv_scalar<MODE_UP>(GemmConvP, int, hipStream_t);
+
+template <int MODE, int M_REP, int J>
+static hipError_t launch_wgrad_cfg(WgradP& p, int B, int bpb, hipStream_t st) {
+  constexpr int MT = 16 * M_REP;
+  auto k = conv_wgrad_kernel<MODE, M_REP, J>;
+  static bool once = false;
+  if (!once) { allow_big_lds(k); once = true; }
+  const int mtiles = (p.R + MT - 1) / MT, ctiles = (p.Cred + 15) / 16;
+  const int nbg = (B + bpb - 1) / bpb;
+  dim3 grid(nbg * p.ntiles, p.groups * mtiles * ctiles, 1);
+  size_t lds = (size_t)(MT * p.AS + 16 * p.XS) * sizeof(float);
+  size_t red = (size_t)M_REP * J * 4 * 64 * sizeof(float);
+  if (red > lds) lds = red;
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p, bpb, B);
+  return hipGetLastError();
+}
+
+template <int MODE, int M_REP>
+static hipError_t launch_wgrad_j(WgradP& p, int B, int bpb, hipStream_t st) {
+  switch (p.J) {
+    case 1: return launch_wgrad_cfg<MODE, M_REP, 1>(p, B, bpb, st);
+    case 2: return launch_wgrad_cfg<MODE, M_REP, 2>(p, B, bpb, st);
+    case 3: return launch_wgrad_cfg<MODE, M_REP, 3>(p, B, bpb, st);
+    case 5: return launch_wgrad_cfg<MODE, M_REP, 5>(p, B, bpb, st);
+    case 7: return launch_wgrad_cfg<MODE, M_REP, 7>(p, B, bpb, st);
+    case 11: return launch_wgrad_cfg<MODE, M_REP, 11>(p, B, bpb, st);
+    default: return hipErrorInvalidValue;
+  }
+}
+
+bool wgrad_mfma_supported(int J) { return J == 1 || J == 2 || J == 3 || J == 5 || J == 7 || J == 11; }
+
+// Geometry shared by the workspace query and the launch. Returns number of slabs.
+int wgrad_geometry(WgradP& p, int B, int* bpb_out) {
+  const bool direct = p.mode == MODE_DIRECT;
+  int NTc = p.N >= 512 ? 512 : ((p.N + 15) / 16) * 16;
+  if (NTc < 16) NTc = 16;
+  const int M_REP = p.R > 16 ? 2 : 1;
+  if (M_REP == 2 && NTc > 256) NTc = 256;
+  p.NTc = NTc;
+  p.ntiles = (p.N + NTc - 1) / NTc;
+  const int hi = direct ? (p.J - 1) * p.d - p.pad : p.J - 1;
+  p.lo = direct ? -p.pad : 0;
+  p.span = NTc + hi - p.lo;
+  p.XS = ((p.span + 31) / 32) * 32 + 2;
+  p.AS = ((NTc + 31) / 32) * 32 + 2;
+  // short sequences: loop the whole batch inside one block so that only one slab is written
+  int bpb = (p.N <= 128) ? B : 1;
+  *bpb_out = bpb;
+  return ((B + bpb - 1) / bpb) * p.ntiles;
+}
+
+template <int MODE>
+hipError_t launch_conv_wgrad(WgradP p, int B, int bpb, hipStream_t st) {
+  if (p.R > 16) return launch_wgrad_j<MODE, 2>(p, B, bpb, st);
+  return launch_wgrad_j<MODE, 1>(p, B, bpb, st);
+}
+template hipError_t launch_conv_wgrad<MODE_DIRECT>(WgradP, int, int, hipStream_t);
+template hipError_t launch_conv_wgrad<MODE_DOWN>(WgradP, int, int, hipStream_t);
+
+template <int MODE>
+hipError_t launch_conv_wgrad_scalar(WgradP p, int B, long nweights, float* dw, hipStream_t st) {
+  hipLaunchKernelGGL(conv_wgrad_scalar_kernel<MODE>, dim3((unsigned)nweights), dim3(256), 0, st, p, B, dw);
+  return hipGetLastError();
+}
+template hipError_t launch_conv_wgrad_scalar<MODE_DIRECT>(WgradP, int, long, float*, hipStream_t);
+template hipError_t launch_conv_wgrad_scalar<MODE_DOWN>(WgradP, int, long, float*, hipStream_t);
+
+hipError_t launch_slab_reduce(const float* slab, int nslab, long stride, long n, float* dw, hipStream_t st) {
+  int gx = (int)((n + 255) / 256); if (gx > 2048) gx = 2048; if (gx < 1) gx = 1;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(gx), dim3(256), 0, st, slab, nslab, stride, n, dw);
+  return hipGetLastError();
+}
+
+hipError_t launch_bias_grad(const Opnd& a, int N, int Ctot, int B, float* dbias, hipStream_t st) {
+  hipLaunchKernelGGL(conv_bias_grad_kernel, dim3(Ctot, B), dim3(256), 0, st, a, N, Ctot, dbias);
+  return hipGetLastError();
+}
+
+}  // namespace tdvc

@@ -1,0 +1,521 @@
+// Non-convolution kernels of the train step: multi-tensor weight norm, fused AdamW, channel
+// L2-normalise, class-channel gather, conditioning concat, conditional instance norm, loss
+// reductions (LSGAN MSE-to-constant, L1 pairs, log-mel helpers, contrastive InfoNCE).
+// All are HBM-bound streaming / reduction kernels: coalesced along T, wave64 shuffle reductions.
+#include "../../include/tdvc.h"
+#include "api_util.h"
+#include <math.h>
+
+static thread_local char g_err[256] = "";
+int tdvc_fail(int code, const char* msg) {
+  snprintf(g_err, sizeof(g_err), "%s", msg ? msg : "");
+  return code;
+}
+extern "C" const char* tdvc_last_error(void) { return g_err; }
+extern "C" int tdvc_version(void) { return 100; }
+
+namespace {
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+// block-wide sum for 256-thread blocks; result valid in every thread
+__device__ __forceinline__ float block_sum(float v, float* sh /* >= 4 floats */) {
+  v = wave_sum(v);
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+  __syncthreads();
+  float r = 0.f;
+  const int nw = (blockDim.x + 63) >> 6;
+  for (int i = 0; i < nw; ++i) r += sh[i];
+  return r;
+}
+
+// ------------------------------------------------------------------------------ weight norm
+// one wave per weight row (dim-0 slice); rows of all tensors of a model in one launch
+__global__ __launch_bounds__(256) void wn_fwd_kernel(const float* __restrict__ params, float* __restrict__ w,
+                                                     const int64_t* row_voff, const int64_t* row_goff,
+                                                     const int64_t* row_woff, const int32_t* row_len, int nrows) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const int lane = threadIdx.x & 63;
+  const float* v = params + row_voff[row];
+  float* o = w + row_woff[row];
+  const int n = row_len[row];
+  float ss = 0.f;
+  for (int i = lane; i < n; i += 64) { float t = v[i]; ss += t * t; }
+  ss = wave_sum(ss);
+  const float sc = params[row_goff[row]] / sqrtf(ss);
+  for (int i = lane; i < n; i += 64) o[i] = v[i] * sc;
+}
+
+__global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ params, const float* __restrict__ dw,
+                                                     float* __restrict__ grads, const int64_t* row_voff,
+                                                     const int64_t* row_goff, const int64_t* row_woff,
+                                                     const int32_t* row_len, int nrows, int accumulate) {
+  const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= nrows) return;
+  const int lane = threadIdx.x & 63;
+  const float* v = params + row_voff[row];
+  const float* d = dw + row_woff[row];
+  float* dv = grads + row_voff[row];
+  const int n = row_len[row];
+  float ss = 0.f, dot = 0.f;
+  for (int i = lane; i < n; i += 64) { float t = v[i]; ss += t * t; dot += t * d[i]; }
+  ss = wave_sum(ss); dot = wave_sum(dot);
+  const float nrm = sqrtf(ss), g = params[row_goff[row]];
+  const float a = g / nrm, bcoef = g * dot / (nrm * ss);
+  for (int i = lane; i < n; i += 64) {
+    const float t = a * d[i] - bcoef * v[i];
+    dv[i] = accumulate ? dv[i] + t : t;
+  }
+  if (lane == 0) {
+    float* dg = grads + row_goff[row];
+    const float t = dot / nrm;
+    dg[0] = accumulate ? dg[0] + t : t;
+  }
+}
+
+// ------------------------------------------------------------------------------ AdamW
+__global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
+                                                    float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
+                                                    float wd, float bc1, float bc2_sqrt, float gscale, const int32_t* step_ptr) {
+  if (step_ptr) {   // device-resident step counter: keeps a captured hipGraph valid across replays
+    const float st = (float)step_ptr[0];
+    bc1 = 1.f - powf(b1, st); bc2_sqrt = sqrtf(1.f - powf(b2, st));
+  }
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float gr = g[i] * gscale;
+    float pv = p[i] * (1.f - lr * wd);
+    const float mv = b1 * m[i] + (1.f - b1) * gr;
+    const float vv = b2 * v[i] + (1.f - b2) * gr * gr;
+    const float denom = sqrtf(vv) / bc2_sqrt + eps;
+    pv -= (lr / bc1) * (mv / denom);
+    p[i] = pv; m[i] = mv; v[i] = vv;
+  }
+}
+
+// ------------------------------------------------------------------------------ element-wise
+__global__ __launch_bounds__(256) void l2norm_fwd_kernel(const float* x, float* y, float* inv, int C, int T, float eps) {
+  const int t = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (t >= T) return;
+  const float* xb = x + (long)b * C * T + t;
+  float ss = 0.f;
+  for (int c = 0; c < C; ++c) { float v = xb[(long)c * T]; ss += v * v; }
+  const float r = 1.f / fmaxf(sqrtf(ss), eps);
+  inv[(long)b * T + t] = r;
+  float* yb = y + (long)b * C * T + t;
+  for (int c = 0; c < C; ++c) yb[(long)c * T] = xb[(long)c * T] * r;
+}
+
+__global__ __launch_bounds__(256) void l2norm_bwd_kernel(const float* y, const float* inv, const float* dy, float* dx, int C, int T) {
+  const int t = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (t >= T) return;
+  const long o = (long)b * C * T + t;
+  float dot = 0.f;
+  for (int c = 0; c < C; ++c) dot += dy[o + (long)c * T] * y[o + (long)c * T];
+  const float r = inv[(long)b * T + t];
+  for (int c = 0; c < C; ++c) dx[o + (long)c * T] = (dy[o + (long)c * T] - y[o + (long)c * T] * dot) * r;
+}
+
+__global__ __launch_bounds__(256) void gather_ch_kernel(const float* x, const int64_t* label, float* y, int C, int T, int bwd) {
+  const int t = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (t >= T) return;
+  const int l = (int)label[b];
+  if (!bwd) y[(long)b * T + t] = x[((long)b * C + l) * T + t];
+  else for (int c = 0; c < C; ++c) y[((long)b * C + c) * T + t] = (c == l) ? x[(long)b * T + t] : 0.f;
+}
+
+__global__ __launch_bounds__(256) void concat_cond_kernel(const float* emb, const float* exc, float* c, int Ce, int Cx, int T) {
+  const int t = blockIdx.x * 256 + threadIdx.x, ch = blockIdx.y, b = blockIdx.z;
+  if (t >= T) return;
+  const float v = ch < Ce ? emb[(long)b * Ce + ch] : exc[((long)b * Cx + (ch - Ce)) * T + t];
+  c[((long)b * (Ce + Cx) + ch) * T + t] = v;
+}
+
+// demb[b][ch] (+)= sum_t dc[b][ch][t]  (one block per (ch,b)); dexc = copy of the tail channels
+__global__ __launch_bounds__(256) void concat_cond_bwd_kernel(const float* dc, float* demb, float* dexc, int Ce, int Cx, int T, int acc) {
+  __shared__ float sh[4];
+  const int ch = blockIdx.x, b = blockIdx.y;
+  const float* src = dc + ((long)b * (Ce + Cx) + ch) * T;
+  if (ch < Ce) {
+    float s = 0.f;
+    for (int t = threadIdx.x; t < T; t += 256) s += src[t];
+    s = block_sum(s, sh);
+    if (threadIdx.x == 0) { float* d = demb + (long)b * Ce + ch; *d = acc ? *d + s : s; }
+  } else {
+    float* dst = dexc + ((long)b * Cx + (ch - Ce)) * T;
+    for (int t = threadIdx.x; t < T; t += 256) dst[t] = src[t];
+  }
+}
+
+__global__ __launch_bounds__(256) void axpby_kernel(const float* a, const float* b, float* y, float alpha, float beta, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    y[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
+}
+
+__global__ __launch_bounds__(256) void fill_kernel(float* y, float v, long n) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = v;
+}
+
+// ------------------------------------------------------------------------------ conditional instance norm
+// one block per (c, b) row; biased variance, eps inside the sqrt (nn.InstanceNorm1d, affine=False)
+__global__ __launch_bounds__(256) void cin_fwd_kernel(const float* x, const float* gb, float* y, float* mean, float* rstd,
+                                                      int C, int T, int Tg, float eps) {
+  __shared__ float sh[4];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const float* xr = x + ((long)b * C + c) * T;
+  float s = 0.f;
+  for (int t = threadIdx.x; t < T; t += 256) s += xr[t];
+  const float mu = block_sum(s, sh) / T;
+  float q = 0.f;
+  for (int t = threadIdx.x; t < T; t += 256) { float d = xr[t] - mu; q += d * d; }
+  const float rs = rsqrtf(block_sum(q, sh) / T + eps);
+  if (threadIdx.x == 0) { mean[(long)b * C + c] = mu; rstd[(long)b * C + c] = rs; }
+  const float* ga = gb + ((long)b * 2 * C + c) * Tg;
+  const float* be = gb + ((long)b * 2 * C + C + c) * Tg;
+  float* yr = y + ((long)b * C + c) * T;
+  for (int t = threadIdx.x; t < T; t += 256) {
+    const int tg = Tg == 1 ? 0 : t;
+    yr[t] = (1.f + ga[tg]) * ((xr[t] - mu) * rs) + be[tg];
+  }
+}
+
+__global__ __launch_bounds__(256) void cin_bwd_kernel(const float* x, const float* gb, const float* dy, const float* mean,
+                                                      const float* rstd, float* dx, float* dgb, int C, int T, int Tg) {
+  __shared__ float sh[4];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const long ro = ((long)b * C + c) * T;
+  const float mu = mean[(long)b * C + c], rs = rstd[(long)b * C + c];
+  const float* ga = gb + ((long)b * 2 * C + c) * Tg;
+  float* dga = dgb + ((long)b * 2 * C + c) * Tg;
+  float* dbe = dgb + ((long)b * 2 * C + C + c) * Tg;
+  float s1 = 0.f, s2 = 0.f, sg = 0.f, sb = 0.f;
+  for (int t = threadIdx.x; t < T; t += 256) {
+    const int tg = Tg == 1 ? 0 : t;
+    const float xh = (x[ro + t] - mu) * rs, d = dy[ro + t], dh = d * (1.f + ga[tg]);
+    s1 += dh; s2 += dh * xh;
+    if (Tg == 1) { sg += d * xh; sb += d; } else { dga[t] = d * xh; dbe[t] = d; }
+  }
+  const float m1 = block_sum(s1, sh) / T, m2 = block_sum(s2, sh) / T;
+  if (Tg == 1) {
+    const float tg_ = block_sum(sg, sh), tb_ = block_sum(sb, sh);
+    if (threadIdx.x == 0) { dga[0] = tg_; dbe[0] = tb_; }
+  }
+  for (int t = threadIdx.x; t < T; t += 256) {
+    const int tg = Tg == 1 ? 0 : t;
+    const float xh = (x[ro + t] - mu) * rs, dh = dy[ro + t] * (1.f + ga[tg]);
+    dx[ro + t] = rs * (dh - m1 - xh * m2);
+  }
+}
+
+// ------------------------------------------------------------------------------ loss reductions
+// loss_out[0] += weight * mean((x - target)^2)
+__global__ __launch_bounds__(256) void mse_const_fwd_kernel(const float* x, long n, float target, float w_over_n, float* out) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) { float d = x[i] - target; s += d * d; }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) atomicAdd(out, s * w_over_n);
+}
+__global__ __launch_bounds__(256) void mse_const_bwd_kernel(const float* x, long n, float target, float w2_over_n, const float* up, float* dx) {
+  const float u = up ? up[0] : 1.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) dx[i] = (x[i] - target) * w2_over_n * u;
+}
+__global__ __launch_bounds__(256) void l1_fwd_kernel(const float* a, const float* b, long n, float w_over_n, float* out) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += fabsf(a[i] - b[i]);
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) atomicAdd(out, s * w_over_n);
+}
+__global__ __launch_bounds__(256) void l1_bwd_kernel(const float* a, const float* b, long n, float w_over_n, const float* up, float* da, int acc) {
+  const float u = (up ? up[0] : 1.f) * w_over_n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float d = a[i] - b[i];
+    const float g = d > 0.f ? u : (d < 0.f ? -u : 0.f);
+    da[i] = acc ? da[i] + g : g;
+  }
+}
+
+// ---- log-mel helpers (the two GEMMs run on the conv kernels: STFT = strided conv with the
+// windowed DFT basis as weight, mel projection = 1x1 conv with the filterbank as weight)
+__global__ __launch_bounds__(256) void reflect_pad_kernel(const float* x, float* y, int T, int pad) {
+  const int Tp = T + 2 * pad, b = blockIdx.y;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < Tp; i += gridDim.x * 256) {
+    int q = i - pad;
+    if (q < 0) q = -q; else if (q >= T) q = 2 * (T - 1) - q;
+    y[(long)b * Tp + i] = x[(long)b * T + q];
+  }
+}
+__global__ __launch_bounds__(256) void reflect_pad_bwd_kernel(const float* dy, float* dx, int T, int pad) {
+  const int Tp = T + 2 * pad, b = blockIdx.y;
+  for (int q = blockIdx.x * 256 + threadIdx.x; q < T; q += gridDim.x * 256) {
+    float s = dy[(long)b * Tp + q + pad];
+    if (q >= 1 && q <= pad) s += dy[(long)b * Tp + pad - q];
+    if (q >= T - 1 - pad && q <= T - 2) s += dy[(long)b * Tp + pad + 2 * (T - 1) - q];
+    dx[(long)b * T + q] = s;
+  }
+}
+// spec [B][2F][N] (re rows 0..F-1, im rows F..2F-1) -> power [B][F][N]
+__global__ __launch_bounds__(256) void power_fwd_kernel(const float* spec, float* pw, int F, int N, long total) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long b = i / ((long)F * N), r = i - b * (long)F * N;
+    const float re = spec[b * 2L * F * N + r], im = spec[b * 2L * F * N + (long)F * N + r];
+    pw[i] = re * re + im * im;
+  }
+}
+__global__ __launch_bounds__(256) void power_bwd_kernel(const float* spec, const float* dpw, float* dspec, int F, int N, long total) {
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < total; i += (long)gridDim.x * 256) {
+    const long b = i / ((long)F * N), r = i - b * (long)F * N;
+    const long o = b * 2L * F * N + r;
+    const float g = 2.f * dpw[i];
+    dspec[o] = g * spec[o];
+    dspec[o + (long)F * N] = g * spec[o + (long)F * N];
+  }
+}
+// loss += w/n * sum |log(max(a,floor)) - log(max(b,floor))|
+__global__ __launch_bounds__(256) void log_l1_fwd_kernel(const float* a, const float* b, long n, float floor_, float w_over_n, float* out) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
+    s += fabsf(logf(fmaxf(a[i], floor_)) - logf(fmaxf(b[i], floor_)));
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) atomicAdd(out, s * w_over_n);
+}
+__global__ __launch_bounds__(256) void log_l1_bwd_kernel(const float* a, const float* b, long n, float floor_, float w_over_n, const float* up, float* da) {
+  const float u = (up ? up[0] : 1.f) * w_over_n;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const float av = a[i];
+    const float d = logf(fmaxf(av, floor_)) - logf(fmaxf(b[i], floor_));
+    const float sg = d > 0.f ? 1.f : (d < 0.f ? -1.f : 0.f);
+    da[i] = av > floor_ ? sg * u / av : 0.f;     // clamp passes gradient only above the floor
+  }
+}
+
+// ------------------------------------------------------------------------------ contrastive InfoNCE
+// One block per (direction, sample): stages Z = anchor-side embedding [C][T] in LDS, loops over t.
+// logits[k] = cos(A[:,t], target_k), target_0 = P[:,t] (other side), target_{1+n} = Z[:, neg(t,n)] (detached).
+// dA / dP accumulate with atomics (each tensor is anchor in one direction and positive in the other).
+__global__ __launch_bounds__(128) void contrastive_kernel(const float* X, const float* Y, const int32_t* idx_x, const int32_t* idx_y,
+                                                          int C, int T, int N, float coef, float* loss, float* dX, float* dY) {
+  extern __shared__ float sm[];
+  float* Z = sm;                 // [C][T]
+  float* zn = Z + C * T;         // [T] column norms of Z
+  float* cs = zn + T;            // [N+1] cosines (logits)
+  float* dl = cs + N + 1;        // [N+1] dlogits * coef
+  float* av = dl + N + 1;        // [C] anchor (normalised)
+  float* pv = av + C;            // [C] positive (normalised)
+  float* red = pv + C;           // [8]
+  const int dir = blockIdx.x, b = blockIdx.y, tid = threadIdx.x;
+  const float* A = (dir == 0 ? X : Y) + (long)b * C * T;
+  const float* P = (dir == 0 ? Y : X) + (long)b * C * T;
+  float* dA = (dir == 0 ? dX : dY) + (long)b * C * T;
+  float* dP = (dir == 0 ? dY : dX) + (long)b * C * T;
+  const int32_t* idx = (dir == 0 ? idx_x : idx_y) + (long)b * T * N;
+  for (int i = tid; i < C * T; i += 128) Z[i] = A[i];
+  __syncthreads();
+  for (int t = tid; t < T; t += 128) {
+    float s = 0.f;
+    for (int c = 0; c < C; ++c) { float v = Z[c * T + t]; s += v * v; }
+    zn[t] = fmaxf(sqrtf(s), 1e-8f);
+  }
+  __syncthreads();
+  float loss_acc = 0.f;
+  for (int t = 0; t < T; ++t) {
+    float ps = 0.f;
+    for (int c = tid; c < C; c += 128) { float v = P[c * T + t]; ps += v * v; }
+    ps = wave_sum(ps);
+    if ((tid & 63) == 0) red[tid >> 6] = ps;
+    __syncthreads();
+    const float pn = fmaxf(sqrtf(red[0] + red[1]), 1e-8f), an = zn[t];
+    for (int c = tid; c < C; c += 128) { av[c] = Z[c * T + t] / an; pv[c] = P[c * T + t] / pn; }
+    __syncthreads();
+    for (int k = tid; k <= N; k += 128) {
+      float s = 0.f;
+      if (k == 0) { for (int c = 0; c < C; ++c) s += av[c] * pv[c]; }
+      else {
+        const int j = idx[t * N + k - 1];
+        for (int c = 0; c < C; ++c) s += av[c] * Z[c * T + j];
+        s /= zn[j];
+      }
+      cs[k] = s;
+    }
+    __syncthreads();
+    float mx = -1e30f;
+    for (int k = tid; k <= N; k += 128) mx = fmaxf(mx, cs[k]);
+    for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+    if ((tid & 63) == 0) red[2 + (tid >> 6)] = mx;
+    __syncthreads();
+    mx = fmaxf(red[2], red[3]);
+    float se = 0.f;
+    for (int k = tid; k <= N; k += 128) se += expf(cs[k] - mx);
+    se = wave_sum(se);
+    if ((tid & 63) == 0) red[4 + (tid >> 6)] = se;
+    __syncthreads();
+    se = red[4] + red[5];
+    if (tid == 0) loss_acc += logf(se) + mx - cs[0];
+    float sdc = 0.f;
+    for (int k = tid; k <= N; k += 128) {
+      const float d = (expf(cs[k] - mx) / se - (k == 0 ? 1.f : 0.f)) * coef;
+      dl[k] = d; sdc += d * cs[k];
+    }
+    sdc = wave_sum(sdc);
+    if ((tid & 63) == 0) red[6 + (tid >> 6)] = sdc;
+    __syncthreads();
+    sdc = red[6] + red[7];
+    const float dl0 = dl[0], c0 = cs[0];
+    for (int c = tid; c < C; c += 128) {
+      float ga = dl0 * pv[c];
+      for (int k = 1; k <= N; ++k) { const int j = idx[t * N + k - 1]; ga += dl[k] * Z[c * T + j] / zn[j]; }
+      ga = (ga - sdc * av[c]) / an;
+      atomicAdd(&dA[c * T + t], ga);
+      atomicAdd(&dP[c * T + t], dl0 * (av[c] - c0 * pv[c]) / pn);
+    }
+    __syncthreads();
+  }
+  if (tid == 0) atomicAdd(loss, loss_acc * coef);
+}
+
+}  // namespace
+
+// ================================================================================================ C ABI
+extern "C" int tdvc_weight_norm_fwd(const float* params, float* w, const int64_t* row_voff, const int64_t* row_goff,
+                                    const int64_t* row_woff, const int32_t* row_len, int nrows, void* stream) {
+  if (!params || !w || nrows <= 0) return tdvc_fail(TDVC_EINVAL, "weight_norm_fwd: bad arguments");
+  hipLaunchKernelGGL(wn_fwd_kernel, dim3((nrows + 3) / 4), dim3(256), 0, (hipStream_t)stream, params, w, row_voff, row_goff, row_woff, row_len, nrows);
+  TDVC_CHECK_LAUNCH();
+  return TDVC_OK;
+}
+extern "C" int tdvc_weight_norm_bwd(const float* params, const float* dw, float* grads, const int64_t* row_voff,
+                                    const int64_t* row_goff, const int64_t* row_woff, const int32_t* row_len, int nrows,
+                                    int accumulate, void* stream) {
+  if (!params || !dw || !grads || nrows <= 0) return tdvc_fail(TDVC_EINVAL, "weight_norm_bwd: bad arguments");
+  hipLaunchKernelGGL(wn_bwd_kernel, dim3((nrows + 3) / 4), dim3(256), 0, (hipStream_t)stream, params, dw, grads, row_voff, row_goff, row_woff, row_len, nrows, accumulate);
+  TDVC_CHECK_LAUNCH();
+  return TDVC_OK;
+}
+
+extern "C" int tdvc_adamw(float* p, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                          float eps, float weight_decay, int step, const int32_t* step_dev, float grad_scale, void* stream) {
+  if (!p || !grad || !m || !v || n <= 0 || (step < 1 && !step_dev)) return tdvc_fail(TDVC_EINVAL, "adamw: bad arguments");
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3(tdvc_grid(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, (long)n, lr, beta1, beta2, eps,
+                     weight_decay, bc1, bc2s, grad_scale == 0.f ? 1.f : grad_scale, step_dev);
+  TDVC_CHECK_LAUNCH();
+  return TDVC_OK;
+}
+
+__global__ void inc_i32_kernel(int32_t* p, int32_t by) { if (threadIdx.x == 0) p[0] += by; }
+extern "C" int tdvc_inc_i32(int32_t* p, int32_t by, void* stream) {
+  hipLaunchKernelGGL(inc_i32_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, p, by);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+
+extern "C" int tdvc_l2norm_fwd(const float* x, float* y, float* inv_norm, int B, int C, int T, float eps, void* stream) {
+  hipLaunchKernelGGL(l2norm_fwd_kernel, dim3((T + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, y, inv_norm, C, T, eps);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+extern "C" int tdvc_l2norm_bwd(const float* y, const float* inv_norm, const float* dy, float* dx, int B, int C, int T, void* stream) {
+  hipLaunchKernelGGL(l2norm_bwd_kernel, dim3((T + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, y, inv_norm, dy, dx, C, T);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+extern "C" int tdvc_gather_ch_fwd(const float* x, const int64_t* label, float* y, int B, int C, int T, void* stream) {
+  hipLaunchKernelGGL(gather_ch_kernel, dim3((T + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, x, label, y, C, T, 0);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+extern "C" int tdvc_gather_ch_bwd(const float* dy, const int64_t* label, float* dx, int B, int C, int T, void* stream) {
+  hipLaunchKernelGGL(gather_ch_kernel, dim3((T + 255) / 256, B), dim3(256), 0, (hipStream_t)stream, dy, label, dx, C, T, 1);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+extern "C" int tdvc_concat_cond(const float* emb, const float* exc, float* c, int B, int Ce, int Cx, int T, void* stream) {
+  hipLaunchKernelGGL(concat_cond_kernel, dim3((T + 255) / 256, Ce + Cx, B), dim3(256), 0, (hipStream_t)stream, emb, exc, c, Ce, Cx, T);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+extern "C" int tdvc_concat_cond_bwd(const float* dc, float* demb, float* dexc, int B, int Ce, int Cx, int T, int accumulate_emb, void* stream) {
+  hipLaunchKernelGGL(concat_cond_bwd_kernel, dim3(Ce + Cx, B), dim3(256), 0, (hipStream_t)stream, dc, demb, dexc, Ce, Cx, T, accumulate_emb);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+extern "C" int tdvc_axpby(const float* a, const float* b, float* y, float alpha, float beta, int64_t n, void* stream) {
+  if (n <= 0) return TDVC_OK;
+  hipLaunchKernelGGL(axpby_kernel, dim3(tdvc_grid(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, a, b, y, alpha, beta, (long)n);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+extern "C" int tdvc_fill(float* y, float value, int64_t n, void* stream) {
+  if (n <= 0) return TDVC_OK;
+  hipLaunchKernelGGL(fill_kernel, dim3(tdvc_grid(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, y, value, (long)n);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+
+extern "C" int tdvc_cin_fwd(const float* x, const float* gb, float* y, float* mean, float* rstd, int B, int C, int T, int Tg, float eps, void* stream) {
+  if (Tg != 1 && Tg != T) return tdvc_fail(TDVC_EINVAL, "cin_fwd: Tg must be 1 or T");
+  hipLaunchKernelGGL(cin_fwd_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, x, gb, y, mean, rstd, C, T, Tg, eps);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+extern "C" int tdvc_cin_bwd(const float* x, const float* gb, const float* dy, const float* mean, const float* rstd,
+                            float* dx, float* dgb, int B, int C, int T, int Tg, void* stream) {
+  if (Tg != 1 && Tg != T) return tdvc_fail(TDVC_EINVAL, "cin_bwd: Tg must be 1 or T");
+  hipLaunchKernelGGL(cin_bwd_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, x, gb, dy, mean, rstd, dx, dgb, C, T, Tg);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+
+extern "C" int tdvc_mse_const_fwd(const float* x, int64_t n, float target, float weight, float* loss_out, void* stream) {
+  hipLaunchKernelGGL(mse_const_fwd_kernel, dim3(tdvc_grid(n, 256, 256)), dim3(256), 0, (hipStream_t)stream, x, (long)n, target, weight / (float)n, loss_out);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+extern "C" int tdvc_mse_const_bwd(const float* x, int64_t n, float target, float weight, const float* upstream, float* dx, void* stream) {
+  hipLaunchKernelGGL(mse_const_bwd_kernel, dim3(tdvc_grid(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, x, (long)n, target, 2.f * weight / (float)n, upstream, dx);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+extern "C" int tdvc_l1_fwd(const float* a, const float* b, int64_t n, float weight, float* loss_out, void* stream) {
+  hipLaunchKernelGGL(l1_fwd_kernel, dim3(tdvc_grid(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, a, b, (long)n, weight / (float)n, loss_out);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+extern "C" int tdvc_l1_bwd(const float* a, const float* b, int64_t n, float weight, const float* upstream, float* da, int accumulate, void* stream) {
+  hipLaunchKernelGGL(l1_bwd_kernel, dim3(tdvc_grid(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, a, b, (long)n, weight / (float)n, upstream, da, accumulate);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+
+extern "C" int tdvc_reflect_pad_fwd(const float* x, float* y, int B, int T, int pad, void* stream) {
+  if (pad >= T) return tdvc_fail(TDVC_EINVAL, "reflect_pad: pad must be < T");
+  hipLaunchKernelGGL(reflect_pad_kernel, dim3(tdvc_grid(T + 2 * pad, 256, 256), B), dim3(256), 0, (hipStream_t)stream, x, y, T, pad);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+extern "C" int tdvc_reflect_pad_bwd(const float* dy, float* dx, int B, int T, int pad, void* stream) {
+  if (pad >= T) return tdvc_fail(TDVC_EINVAL, "reflect_pad: pad must be < T");
+  hipLaunchKernelGGL(reflect_pad_bwd_kernel, dim3(tdvc_grid(T, 256, 256), B), dim3(256), 0, (hipStream_t)stream, dy, dx, T, pad);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+extern "C" int tdvc_power_fwd(const float* spec, float* power, int B, int F, int N, void* stream) {
+  const long total = (long)B * F * N;
+  hipLaunchKernelGGL(power_fwd_kernel, dim3(tdvc_grid(total, 256, 2048)), dim3(256), 0, (hipStream_t)stream, spec, power, F, N, total);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+extern "C" int tdvc_power_bwd(const float* spec, const float* dpower, float* dspec, int B, int F, int N, void* stream) {
+  const long total = (long)B * F * N;
+  hipLaunchKernelGGL(power_bwd_kernel, dim3(tdvc_grid(total, 256, 2048)), dim3(256), 0, (hipStream_t)stream, spec, dpower, dspec, F, N, total);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+extern "C" int tdvc_log_l1_fwd(const float* a, const float* b, int64_t n, float floor_, float weight, float* loss_out, void* stream) {
+  hipLaunchKernelGGL(log_l1_fwd_kernel, dim3(tdvc_grid(n, 256, 256)), dim3(256), 0, (hipStream_t)stream, a, b, (long)n, floor_, weight / (float)n, loss_out);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+extern "C" int tdvc_log_l1_bwd(const float* a, const float* b, int64_t n, float floor_, float weight, const float* upstream, float* da, void* stream) {
+  hipLaunchKernelGGL(log_l1_bwd_kernel, dim3(tdvc_grid(n, 256, 1024)), dim3(256), 0, (hipStream_t)stream, a, b, (long)n, floor_, weight / (float)n, upstream, da);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+
+extern "C" int tdvc_contrastive_fwd_bwd(const float* X, const float* Y, const int32_t* idx_x, const int32_t* idx_y, int B, int C, int T, int N,
+                                        float weight, float* loss_out, float* dX, float* dY, void* stream) {
+  if (C <= 0 || T <= 1 || N <= 0) return tdvc_fail(TDVC_EINVAL, "contrastive: bad shape");
+  const size_t lds = (size_t)(C * T + T + 2 * (N + 1) + 2 * C + 8) * sizeof(float);
+  if (lds > 150 * 1024) return tdvc_fail(TDVC_EUNSUPPORTED, "contrastive: embedding tile exceeds LDS");
+  static bool once = false;
+  if (!once) { hipFuncSetAttribute(reinterpret_cast<const void*>(contrastive_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  const float coef = weight / (2.f * (float)B * (float)T);
+  hipLaunchKernelGGL(contrastive_kernel, dim3(2, B), dim3(128), lds, (hipStream_t)stream, X, Y, idx_x, idx_y, C, T, N, coef, loss_out, dX, dY);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}

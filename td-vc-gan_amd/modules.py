@@ -1,0 +1,447 @@
+"""Drop-in `Generator` / `CollaborativeMultibandDiscriminator` / `ConditionalInstanceNorm` /
+`LatentClassifier` modules: the reference's constructor signatures, forward signatures and
+state_dict keys, with every forward/backward FLOP in the HIP kernels.
+
+Reference surface mirrored (file:line under the reference tree):
+  Generator(...)                               model/generator.py:409-508
+  Encoder / Decoder / MRFBlock / FiLMResnetBlock / ExciteDownsampleBlock   :69-111, :141-173, :175-194, :197-406
+  CollaborativeMultibandDiscriminator(...)     model/discriminator.py:77-118 (Discriminator :7-53)
+  ConditionalInstanceNorm(n_channel, n_cond)   model/conditional_instance_norm.py:4-19
+  LatentClassifier(num_classes, C)             model/latent_classifier.py:8-39, model/grad_rev.py:3-17
+Only the configuration space the shipped YAMLs reach is implemented (conv encoder, Identity norm
+layers, weight_norm on, 'target' conditioning); anything else raises NotImplementedError.
+"""
+import math
+
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from . import ops
+from .arena import ConvSlot, ParamArena
+from .ops import PRE_LRELU, PRE_NONE, ConvSpec
+
+SLOPE = 0.2
+MRF_KERNELS = (3, 7, 11)
+MRF_DILATIONS = (1, 3, 5)
+
+
+# ------------------------------------------------------------------------------- filters
+def kaiser_filter_even(L_, w):
+    """L_+1 taps (util/__init__.py:104-113): sinc(w) * kaiser(beta 2.5), unit DC gain."""
+    n = torch.arange(-(L_ // 2), L_ // 2 + 1, dtype=torch.float32)
+    f = torch.sin(math.pi * w * n) / (math.pi * n + 1e-8)
+    f[n.numel() // 2] = w
+    f = f * torch.kaiser_window(L_ + 1, False, 2.5)
+    return f / f.sum()
+
+
+def kaiser_filter_odd(L_, fc, beta=2.5):
+    """L_ taps, L_ odd (util/dsp.py:5-16)."""
+    if L_ % 2 == 0:
+        raise Exception('Even length filter not implemented')
+    h = (L_ - 1) // 2
+    n = torch.arange(-h, h + 1, dtype=torch.float32)
+    f = torch.sin(math.pi * fc * n) / (math.pi * n + 1e-8)
+    f[h] = fc
+    f = f * torch.kaiser_window(L_, False, beta)
+    return f / f.sum()
+
+
+# ------------------------------------------------------------------------------- parameter holders
+class ConvParams(nn.Module):
+    """Parameters of one conv with the reference's key names: weight_norm -> bias, weight_g, weight_v;
+    plain -> weight, bias. For ConvTranspose1d dim 0 of the weight is the INPUT channel axis (Q12)."""
+
+    def __init__(self, cin, cout, k, stride=1, pad=0, dil=1, groups=1, reflect=False, bias=True, wn=True,
+                 transposed=False, out_pad=0):
+        super().__init__()
+        self.spec = ConvSpec(cin, cout, k, stride, pad, dil, groups, reflect, transposed, out_pad)
+        shape = (cin, cout // groups, k) if transposed else (cout, cin // groups, k)
+        fan_in = shape[1] * k
+        bound = 1.0 / math.sqrt(fan_in)
+        w = torch.empty(shape).uniform_(-bound, bound)
+        self.has_bias, self.wn = bias, wn
+        if not wn:
+            self.weight = nn.Parameter(w)
+        if bias:
+            self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
+        if wn:
+            self.weight_g = nn.Parameter(w.reshape(shape[0], -1).norm(dim=1).reshape(shape[0], 1, 1))
+            self.weight_v = nn.Parameter(w)
+
+    def forward(self, x, pre=PRE_NONE, post=L.POST_NONE, add=None):
+        return ops.conv(x, self.spec, pre, post, add)
+
+
+class LinearParams(nn.Module):
+    """nn.Linear keys (weight [out,in], bias); runs as a K=1 conv over a length-1 sequence."""
+
+    def __init__(self, cin, cout):
+        super().__init__()
+        bound = 1.0 / math.sqrt(cin)
+        self.weight = nn.Parameter(torch.empty(cout, cin).uniform_(-bound, bound))
+        self.bias = nn.Parameter(torch.empty(cout).uniform_(-bound, bound))
+        self.spec = ConvSpec(cin, cout, 1)
+        self.has_bias, self.wn = True, False
+
+    def forward(self, x):
+        return ops.conv(x.unsqueeze(2), self.spec).squeeze(2)
+
+
+class FixedFIR:
+    """Constant (non-trainable, non-persistent) FIR filter run through the conv kernels."""
+
+    def __init__(self, taps: torch.Tensor, channels, stride, pad):
+        self.taps = taps.reshape(1, 1, -1).expand(channels, 1, -1).contiguous()
+        self.spec = ConvSpec(channels, channels, taps.numel(), stride, pad, 1, channels)
+        self.dev_taps = None
+
+    def to(self, device):
+        if self.dev_taps is None or self.dev_taps.device != device:
+            self.dev_taps = self.taps.to(device)
+            self.spec.slot = ConvSlot(self.dev_taps.data_ptr(), 0, 0, 0, trainable=False)
+
+    def __call__(self, x):
+        self.to(x.device)
+        return ops.conv(x, self.spec)
+
+
+class ArenaModule(nn.Module):
+    """Top-level model: owns the flat arenas and binds every conv's slot to them."""
+    dead_prefixes = ()
+
+    def _init_arena_state(self):
+        self._arena = None
+        self._frozen_weights = False
+
+    @property
+    def arena(self) -> ParamArena:
+        return self._arena
+
+    def ensure_arena(self, device):
+        device = torch.device(device)
+        if device.type != 'cuda':
+            raise L.TdvcError('tdvc modules run on an MI355X device only (no CPU fallback): move inputs to cuda')
+        ps = list(self.parameters())
+        if self._arena is not None and self._arena.device == device and self._arena.owns(ps[0]) and self._arena.owns(ps[-1]):
+            return self._arena
+        L.lib()   # fail loudly before touching anything if the extension is missing
+        self._arena = ParamArena(self, device, self.dead_prefixes)
+        for name, m in self.named_modules():
+            if isinstance(m, (ConvParams, LinearParams)):
+                if any((name + '.').startswith(d) for d in self.dead_prefixes):
+                    continue
+                m.spec.slot = self._arena.slot(name, m.has_bias)
+        self._arena.materialize()
+        return self._arena
+
+    def begin_forward(self, x):
+        a = self.ensure_arena(x.device)
+        if not self._frozen_weights:
+            a.materialize()
+        return a
+
+    def weights_frozen(self, flag=True):
+        """While set, forward() reuses the effective weights of the last ParamArena.materialize()."""
+        self._frozen_weights = flag
+
+
+# ------------------------------------------------------------------------------- generator blocks
+class FiLMResnetBlock(nn.Module):
+    def __init__(self, n_channel, n_cond_const, n_cond_var=0, dilation=1, kernel_size=3):
+        super().__init__()
+        pad = (kernel_size * dilation - dilation) // 2
+        self.conv = nn.Sequential(nn.LeakyReLU(SLOPE), ConvParams(n_channel, n_channel, kernel_size, pad=pad, dil=dilation, reflect=True))
+        self.posconv = nn.Sequential(nn.LeakyReLU(SLOPE), ConvParams(n_channel, n_channel, 1))
+        self.has_cond = bool(n_cond_const or n_cond_var)
+        if self.has_cond:
+            nc = n_cond_const + n_cond_var
+            self.cond_var = nn.Sequential(ConvParams(nc, nc, 3, pad=1), nn.LeakyReLU(SLOPE), ConvParams(nc, n_channel * 2, 3, pad=1))
+        self.shortcut = nn.Identity()
+
+    def forward(self, x, c=None, acc=None, scale=1.0):
+        gb = None
+        if c is not None:
+            cv = self.cond_var[0](c)
+            gb = self.cond_var[2](cv, pre=PRE_LRELU)
+        return ops.film_block(x, gb, acc, self.conv[1].spec, self.posconv[1].spec, scale)
+
+
+class MRFBlock(nn.Module):
+    def __init__(self, n_channel, n_cond_const=0, n_cond_var=0):
+        super().__init__()
+        self.blocks = nn.ModuleList([nn.ModuleList([FiLMResnetBlock(n_channel, n_cond_const, n_cond_var, d, k)
+                                                    for d in MRF_DILATIONS]) for k in MRF_KERNELS])
+
+    def forward(self, x, c=None):
+        acc, s = None, 1.0 / len(self.blocks)
+        for branch in self.blocks:
+            xs = x
+            for j, blk in enumerate(branch):
+                last = j == len(branch) - 1
+                xs = blk(xs, c, acc if last else None, s if last else 1.0)
+            acc = xs
+        return acc
+
+
+class ExciteDownsampleBlock(nn.Module):
+    def __init__(self, in_channel, out_channel, scale_factor, n_layers=2, kernel_size=5):
+        super().__init__()
+        r = scale_factor
+        self.scale_factor = r
+        self.block = nn.ModuleList([ConvParams(in_channel, out_channel, 2 * r, stride=r, pad=r // 2)])
+        for _ in range(n_layers):
+            self.block += [nn.LeakyReLU(SLOPE), ConvParams(out_channel, out_channel, kernel_size, pad=(kernel_size - 1) // 2)]
+        self.shortcut = ConvParams(in_channel, out_channel, 1, wn=False)
+        self.fir = FixedFIR(kaiser_filter_even(16 * r, 1.0 / r), out_channel, r, 8 * r)
+
+    def forward(self, x):
+        sh = self.fir(self.shortcut(x))
+        h = self.block[0](x)
+        h = self.block[2](h, pre=PRE_LRELU)
+        return self.block[4](h, pre=PRE_LRELU, add=sh)
+
+
+class Encoder(nn.Module):
+    def __init__(self, ratios, channels, embedding_dim):
+        super().__init__()
+        m = nn.ModuleList([ConvParams(1, channels[0], 7, pad=3, reflect=True)])
+        for i, r in enumerate(ratios):
+            m += [nn.Identity(), nn.LeakyReLU(SLOPE),
+                  ConvParams(channels[i], channels[i + 1], 2 * r, stride=r, pad=r // 2 + r % 2),
+                  MRFBlock(channels[i + 1])]
+        m += [nn.LeakyReLU(SLOPE), ConvParams(channels[-1], channels[-1], 7, pad=3)]
+        if embedding_dim:
+            m += [nn.LeakyReLU(SLOPE), ConvParams(channels[-1], embedding_dim, 7, pad=3, bias=False)]
+        self.encoder = m
+        self._top = None     # set by Generator: lets `G.encoder(x)` (train.py:405) find the arena
+
+    def forward(self, x, c=None):
+        if self._top is not None:
+            self._top().begin_forward(x)
+        x = x.contiguous().float()
+        first = True
+        for mod in self.encoder:
+            if isinstance(mod, ConvParams):
+                x = mod(x, pre=PRE_NONE if first else PRE_LRELU)
+                first = False
+            elif isinstance(mod, MRFBlock):
+                x = mod(x)
+        return ops.L2NormFn.apply(x)
+
+
+class Decoder(nn.Module):
+    def __init__(self, ratios, channels, conditional_dim, embedding_dim):
+        super().__init__()
+        self.upsample_ratios = list(ratios)
+        excite = [8] * (len(ratios) + 1)
+        sub_out = [False, True, True, False]
+        m = nn.ModuleList()
+        if embedding_dim:
+            m += [nn.LeakyReLU(SLOPE), ConvParams(embedding_dim, channels[0], 7, pad=3, bias=False)]
+        m += [nn.LeakyReLU(SLOPE), ConvParams(channels[0], channels[0], 7, pad=3)]
+        self.upsample_idxs = []
+        self.subsample_out_layers = nn.ModuleList()
+        for i, r in enumerate(ratios):
+            m += [nn.Identity(), nn.LeakyReLU(SLOPE),
+                  ConvParams(channels[i], channels[i + 1], 2 * r, stride=r, pad=r // 2 + r % 2, transposed=True, out_pad=r % 2)]
+            self.upsample_idxs.append(len(m))
+            m += [MRFBlock(channels[i + 1], conditional_dim, excite[i + 1])]
+            if i < len(sub_out) and sub_out[i]:
+                self.subsample_out_layers.append(nn.Sequential(nn.LeakyReLU(SLOPE), ConvParams(channels[i + 1], 1, 7, pad=3, reflect=True), nn.Tanh()))
+            else:
+                self.subsample_out_layers.append(None)
+        m += [nn.Identity(), nn.LeakyReLU(SLOPE), ConvParams(channels[-1], 1, 7, pad=3, reflect=True), nn.Tanh()]
+        self.upsample_idxs.append(len(m))
+        self.decoder = m
+        self.excite_downsample = nn.ModuleList()
+        for r, ci, co in zip(ratios, excite[:-1], excite[1:]):
+            self.excite_downsample += [ExciteDownsampleBlock(ci, co, r)]
+        self.excite_downsample += [ConvParams(1, excite[0], 7, pad=3, reflect=True)]
+
+    def get_scaled_conditioning(self, c):
+        """Fine -> coarse excitation pyramid. The coarsest stage (excite_downsample[0]) is never consumed by
+        forward(): it is not computed and its parameters keep grad None."""
+        out = []
+        mods = list(reversed(self.excite_downsample))
+        for mod in mods[:-1]:
+            c = mod(c)
+            out.append(c)
+        return out
+
+    def forward(self, x, c=None, c_var=None, out_subsample=False):
+        if c_var is None:
+            # the reference raises UnboundLocalError here (Q8); be explicit instead
+            raise RuntimeError('Decoder.forward needs c_var (the F0 excitation): the reference has no path without it')
+        pyr = self.get_scaled_conditioning(c_var.contiguous().float())
+        subs = []
+        scale = 0
+        final_conv = len(self.decoder) - 2
+        for i, mod in enumerate(self.decoder):
+            if i == self.upsample_idxs[scale]:
+                head = self.subsample_out_layers[scale]
+                if head is not None:
+                    subs.append(head[1](x, pre=PRE_LRELU, post=L.POST_TANH))
+                cond = ops.ConcatCondFn.apply(c, pyr[len(pyr) - 1 - scale])
+                scale += 1
+            if isinstance(mod, MRFBlock):
+                x = mod(x, cond)
+            elif isinstance(mod, ConvParams):
+                x = mod(x, pre=PRE_LRELU, post=L.POST_TANH if i == final_conv else L.POST_NONE)
+        if out_subsample:
+            return x, subs
+        return x
+
+
+class Generator(ArenaModule):
+    dead_prefixes = ('decoder.excite_downsample.0.',)
+
+    def __init__(self, decoder_ratios, decoder_channels, num_bottleneck_layers, num_classes, conditional_dim,
+                 content_dim=None, num_res_blocks=3, num_enc_layers=0, encoder_model=None, norm_layer=None,
+                 weight_norm=None, bot_cond='target', enc_cond=None, dec_cond=None, output_content_emb=False):
+        super().__init__()
+        self._init_arena_state()
+        nls = norm_layer if isinstance(norm_layer, tuple) else (norm_layer,) * 3
+        wns = weight_norm if isinstance(weight_norm, tuple) else (weight_norm,) * 3
+        if any(n is not None for n in nls):
+            raise NotImplementedError('norm layers other than Identity are not reachable from the shipped configs')
+        if any(w != 'weight_norm' for w in wns):
+            raise NotImplementedError('only weight_norm="weight_norm" is implemented')
+        if encoder_model not in (None, 'conv'):
+            raise NotImplementedError('SSL (WavLM) encoder is out of scope of the HIP path (SURVEY §2.1)')
+        if num_bottleneck_layers != 0 or bot_cond != 'target' or enc_cond is not None or dec_cond is None:
+            raise NotImplementedError('only the shipped conditioning layout is implemented '
+                                      '(0 bottleneck layers, encoder unconditioned, decoder on target)')
+        self.output_content_emb = output_content_emb
+        self.decoder = Decoder(decoder_ratios, list(decoder_channels), conditional_dim, content_dim)
+        self.encoder = Encoder(decoder_ratios[::-1], list(decoder_channels)[::-1], content_dim)
+        import weakref
+        self.encoder._top = weakref.ref(self)
+        self.bottleneck = nn.ModuleList()
+        self.embedding = LinearParams(num_classes, conditional_dim)
+
+    def forward(self, x, c_tgt, c_src=None, c_var=None, out_subsample=False):
+        self.begin_forward(x)
+        emb = self.embedding(c_tgt.contiguous().float())
+        top, self.encoder._top = self.encoder._top, None     # arena already prepared for this call
+        try:
+            content = self.encoder(x)
+        finally:
+            self.encoder._top = top
+        if self.output_content_emb:
+            self.content_embedding = content
+        return self.decoder(content, emb, c_var, out_subsample=out_subsample)
+
+
+# ------------------------------------------------------------------------------- discriminator
+class Discriminator(nn.Module):
+    def __init__(self, num_classes, num_layers, num_channels_base, num_channel_mult=4, downsampling_factor=4,
+                 conditional_dim=32, conditional='both'):
+        super().__init__()
+        ds = downsampling_factor
+        self.discriminator = nn.ModuleList()
+        self.discriminator += [nn.Sequential(ConvParams(1, num_channels_base, 15, pad=7, reflect=True), nn.LeakyReLU(SLOPE))]
+        nf = num_channels_base
+        for _ in range(num_layers):
+            nf_prev, nf = nf, min(nf * num_channel_mult, 1024)
+            self.discriminator += [nn.Sequential(ConvParams(nf_prev, nf, ds * 10 + 1, stride=ds, pad=ds * 5,
+                                                            groups=nf_prev // num_channel_mult), nn.LeakyReLU(SLOPE))]
+        self.discriminator += [nn.Sequential(ConvParams(nf, nf, 5, pad=2), nn.LeakyReLU(SLOPE))]
+        self.output = ConvParams(nf, num_classes, 3, pad=1, bias=False)
+
+    def forward(self, x, label_tgt):
+        feats = []
+        for layer in self.discriminator:
+            x = layer[0](x, post=L.POST_LRELU)      # in-place LeakyReLU: the stored map is post-activation
+            feats.append(x)
+        x = self.output(x)
+        return ops.GatherChFn.apply(x, label_tgt), feats
+
+
+class CollaborativeMultibandDiscriminator(ArenaModule):
+    def __init__(self, num_disc, num_classes, num_layers, num_channels_base, num_channel_mult=4, downsampling_factor=4,
+                 conditional_dim=32, conditional='both'):
+        super().__init__()
+        self._init_arena_state()
+        self.discriminators = nn.ModuleList([Discriminator(num_classes, num_layers, num_channels_base, num_channel_mult,
+                                                           downsampling_factor, conditional_dim, conditional)
+                                             for _ in range(num_disc)])
+        self.L = 129
+        self.down = FixedFIR(kaiser_filter_odd(self.L, 0.5, 10), 1, 2, (self.L - 1) // 2)
+
+    def forward(self, x, label_tgt, subscales=[]):
+        self.begin_forward(x)
+        x = x.contiguous().float()
+        ret = []
+        for i, disc in enumerate(self.discriminators):
+            ret.append(disc(x, label_tgt))
+            if i + 1 < len(self.discriminators):     # the reference filters once more and drops the result
+                x = self.down(x)
+        for x_sub, disc in zip(subscales, reversed(self.discriminators)):
+            ret.append(disc(x_sub.contiguous(), label_tgt))
+        out, features = zip(*ret)
+        return list(out), list(features)
+
+    def get_subsamples(self, x):
+        x = x.contiguous().float()
+        ret = []
+        for _ in range(len(self.discriminators) - 1):
+            x = self.down(x)
+            ret.append(x)
+        return list(reversed(ret))
+
+
+# ------------------------------------------------------------------------------- conditional instance norm
+class ConditionalInstanceNorm(ArenaModule):
+    def __init__(self, n_channel, n_cond, n_conf_var=0):
+        super().__init__()
+        self._init_arena_state()
+        self.n_channel = n_channel
+        self.embedding = LinearParams(n_cond, n_channel * 2)
+        self.embedding_conv = ConvParams(n_cond + 1, n_channel * 2, 5, pad=2, wn=False)
+
+    def forward(self, x, c):
+        self.begin_forward(x)
+        if c.dim() == 2:
+            gb = self.embedding(c.contiguous().float()).unsqueeze(2)
+        else:
+            gb = self.embedding_conv(c.contiguous().float())
+        return ops.CinFn.apply(x.contiguous().float(), gb, 1e-5)
+
+
+# ------------------------------------------------------------------------------- latent classifier
+class _GradRev(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, g):
+        return ops.axpby(g.contiguous(), None, -1.0, 0.0)
+
+
+class LatentClassifier(ArenaModule):
+    def __init__(self, num_classes, num_channels_input, num_layers=3, num_channel_mult=2, downsampling_factor=2):
+        super().__init__()
+        self._init_arena_state()
+        ds = downsampling_factor
+        self.classifier = nn.ModuleList([nn.Identity()])
+        nf = num_channels_input
+        for _ in range(num_layers):
+            nf_prev, nf = nf, nf * num_channel_mult
+            self.classifier += [ConvParams(nf_prev, nf, ds * 10 + 1, stride=ds, pad=ds * 5), nn.LeakyReLU(SLOPE)]
+        self.classifier += [ConvParams(nf, nf, 5, pad=2), nn.LeakyReLU(SLOPE)]
+        self.classifier += [ConvParams(nf, num_classes, 3, pad=1, bias=False)]
+
+    def forward(self, x):
+        self.begin_forward(x)
+        x = _GradRev.apply(x.contiguous().float())
+        convs = [m for m in self.classifier if isinstance(m, ConvParams)]
+        for m in convs[:-1]:
+            x = m(x, post=L.POST_LRELU)
+        x = convs[-1](x)
+        # F.avg_pool1d over the full length, as a fixed 1-tap-per-sample FIR: mean over T
+        T = x.shape[2]
+        fir = FixedFIR(torch.full((T,), 1.0 / T), x.shape[1], 1, 0)
+        return fir(x).squeeze(2)

@@ -1,0 +1,322 @@
+"""Autograd operators over the C ABI (libtdvc_hip.so). torch is plumbing here: it owns device
+memory, the stream and the autograd graph; every FLOP runs in the HIP kernels.
+
+Weight gradients do not travel through autograd: each conv's wgrad kernel accumulates straight
+into its model's flat `dW` / `G` arena (arena.py) and ParamArena.finish_grads() — queued to run at
+the end of the backward pass — folds them into (weight_v, weight_g) gradients. That removes ~800
+per-tensor accumulate launches per iteration.
+"""
+import ctypes as C
+
+import torch
+from torch.autograd import Function
+
+from . import _lib as L
+from .arena import ConvSlot
+
+SLOPE = 0.2
+
+
+def _stream(t):
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+class ConvSpec:
+    """Static description of one conv layer + where its tensors live (ConvSlot)."""
+    __slots__ = ('kind', 'cin', 'cout', 'k', 'stride', 'dil', 'pad', 'groups', 'reflect', 'slot', 'out_pad')
+
+    def __init__(self, cin, cout, k, stride=1, pad=0, dil=1, groups=1, reflect=False, transposed=False, out_pad=0):
+        self.kind = L.CONV_TRANSPOSE if transposed else L.CONV
+        self.cin, self.cout, self.k, self.stride, self.dil, self.pad = cin, cout, k, stride, dil, pad
+        self.groups, self.reflect, self.out_pad = groups, int(reflect), out_pad
+        self.slot = None
+
+    def tout(self, tin):
+        if self.kind == L.CONV:
+            return (tin + 2 * self.pad - self.dil * (self.k - 1) - 1) // self.stride + 1
+        return (tin - 1) * self.stride - 2 * self.pad + self.k + self.out_pad
+
+    def desc(self, B, tin):
+        if self.reflect and self.pad >= tin:
+            raise RuntimeError(f'Padding size should be less than the corresponding input dimension, but got: '
+                               f'padding ({self.pad}, {self.pad}) at dimension 2 of input length {tin}')
+        return L.ConvDesc(self.kind, B, self.cin, self.cout, tin, self.tout(tin), self.k, self.stride, self.dil,
+                          self.pad, self.groups, self.reflect)
+
+
+# ------------------------------------------------------------------------------- workspace
+_ws = {}
+
+
+def workspace(device, nbytes):
+    """Grow-only scratch buffer for wgrad slabs (sized during eager warm-up, stable under graph capture)."""
+    buf = _ws.get(device)
+    if buf is None or buf.numel() < nbytes:
+        if torch.cuda.is_current_stream_capturing():
+            raise L.TdvcError('wgrad workspace would have to grow during graph capture: run an eager step first')
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _ws[device] = buf
+    return buf
+
+
+def _xf(kind=L.XF_NONE, slope=SLOPE, scale=1.0, aux=None):
+    if aux is None:
+        return L.Xform(kind, slope, scale, None, 0)
+    return L.Xform(kind, slope, scale, aux.data_ptr(), aux.stride(0))
+
+
+def _bs(t):
+    return t.stride(0)
+
+
+def _check_layout(t):
+    if t.stride(-1) != 1 or (t.dim() == 3 and t.stride(1) != t.shape[2]):
+        raise L.TdvcError('operand must be [B,C,T] with contiguous (C,T) planes')
+
+
+def conv_fwd_raw(spec: ConvSpec, x, x_xf, post=L.POST_NONE, res=None, add=None, out_scale=1.0, out=None, w_ptr=None, b_ptr=None):
+    B, _, tin = x.shape
+    d = spec.desc(B, tin)
+    y = out if out is not None else torch.empty((B, spec.cout, d.Tout), dtype=torch.float32, device=x.device)
+    _check_layout(x); _check_layout(y)
+    a = L.ConvFwdArgs(x.data_ptr(), _bs(x), x_xf, w_ptr if w_ptr is not None else spec.slot.w,
+                      (b_ptr if b_ptr is not None else spec.slot.b) or None,
+                      res.data_ptr() if res is not None else None, _bs(res) if res is not None else 0,
+                      post, SLOPE, out_scale, add.data_ptr() if add is not None else None,
+                      _bs(add) if add is not None else 0, y.data_ptr(), _bs(y))
+    L.check(L.lib().tdvc_conv_fwd(C.byref(d), C.byref(a), _stream(x)))
+    return y
+
+
+def conv_dgrad_raw(spec: ConvSpec, dy, dy_xf, tin, epilogue=L.DG_PLAIN, x_in=None, gb=None, dgb=None, add=None,
+                   add_scale=1.0, out=None):
+    B = dy.shape[0]
+    d = spec.desc(B, tin)
+    dx = out if out is not None else torch.empty((B, spec.cin, tin), dtype=torch.float32, device=dy.device)
+    _check_layout(dy); _check_layout(dx)
+    a = L.ConvDgradArgs(dy.data_ptr(), _bs(dy), dy_xf, spec.slot.w, epilogue,
+                        x_in.data_ptr() if x_in is not None else None, _bs(x_in) if x_in is not None else 0, SLOPE,
+                        gb.data_ptr() if gb is not None else None, _bs(gb) if gb is not None else 0,
+                        dgb.data_ptr() if dgb is not None else None, _bs(dgb) if dgb is not None else 0,
+                        add.data_ptr() if add is not None else None, _bs(add) if add is not None else 0, add_scale,
+                        dx.data_ptr(), _bs(dx))
+    L.check(L.lib().tdvc_conv_dgrad(C.byref(d), C.byref(a), _stream(dy)))
+    return dx
+
+
+def conv_wgrad_raw(spec: ConvSpec, x, x_xf, dy, dy_xf):
+    """Accumulates into the layer's dW / dbias arena slices. No-op for frozen layers / disabled arenas."""
+    s = spec.slot
+    if not s.trainable or (s.arena is not None and not s.arena.wgrad_enabled):
+        return
+    B, _, tin = x.shape
+    d = spec.desc(B, tin)
+    lib = L.lib()
+    nbytes = lib.tdvc_conv_wgrad_workspace(C.byref(d))
+    ws = workspace(x.device, nbytes) if nbytes else None
+    a = L.ConvWgradArgs(x.data_ptr(), _bs(x), x_xf, dy.data_ptr(), _bs(dy), dy_xf, s.dw, s.db or None,
+                        ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0)
+    L.check(lib.tdvc_conv_wgrad(C.byref(d), C.byref(a), _stream(x)))
+    if s.arena is not None:
+        s.arena.queue_finish()
+
+
+PRE_NONE, PRE_LRELU = 0, 1
+
+
+class ConvFn(Function):
+    """y = post(conv(pre(x)) + bias) [+ add].  pre in {none, LeakyReLU}; post in {none, LeakyReLU, tanh}."""
+
+    @staticmethod
+    def forward(ctx, x, add, token, spec, pre, post):
+        x = x.contiguous()
+        xf = _xf(L.XF_LRELU if pre == PRE_LRELU else L.XF_NONE)
+        y = conv_fwd_raw(spec, x, xf, post=post, add=add)
+        ctx.spec, ctx.pre, ctx.post, ctx.tin = spec, pre, post, x.shape[2]
+        ctx.has_add = add is not None
+        ctx.save_for_backward(x, y if post != L.POST_NONE else None)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, y = ctx.saved_tensors
+        spec = ctx.spec
+        dy = dy.contiguous()
+        if ctx.post == L.POST_LRELU:
+            dy_xf = _xf(L.XF_MASK_LRELU, aux=y)
+        elif ctx.post == L.POST_TANH:
+            dy_xf = _xf(L.XF_MASK_TANH, aux=y)
+        else:
+            dy_xf = _xf()
+        x_xf = _xf(L.XF_LRELU if ctx.pre == PRE_LRELU else L.XF_NONE)
+        conv_wgrad_raw(spec, x, x_xf, dy, dy_xf)
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if ctx.pre == PRE_LRELU:
+                dx = conv_dgrad_raw(spec, dy, dy_xf, ctx.tin, L.DG_MASK_LRELU, x_in=x)
+            else:
+                dx = conv_dgrad_raw(spec, dy, dy_xf, ctx.tin, L.DG_PLAIN)
+        return dx, (dy if ctx.has_add else None), None, None, None, None
+
+
+def _token(*specs):
+    """Weight gradients bypass autograd (they accumulate in the arena), so a trainable layer whose input
+    carries no gradient would never get a backward call. A per-arena dummy leaf keeps it in the graph."""
+    if not torch.is_grad_enabled():
+        return None
+    for sp in specs:
+        s = sp.slot
+        if s.trainable and s.arena is not None and s.arena.wgrad_enabled:
+            return s.arena.token
+    return None
+
+
+def conv(x, spec, pre=PRE_NONE, post=L.POST_NONE, add=None):
+    return ConvFn.apply(x, add, _token(spec), spec, pre, post)
+
+
+class FilmBlockFn(Function):
+    """One FiLM residual block, fused (model/generator.py:96-111):
+         h   = conv_kd(lrelu(x)) + b1
+         out = scale * (conv_1x1(lrelu(h*(1+gamma)+beta)) + b2 + x) + acc
+    FiLM is applied while posconv stages its input tile, so h*(1+gamma)+beta never touches HBM; the
+    backward emits dgamma/dbeta from the same dgrad epilogue that applies the LeakyReLU mask.
+    `scale`/`acc` carry the MRF running mean (model/generator.py:192-193)."""
+
+    @staticmethod
+    def forward(ctx, x, gb, acc, token, conv_spec, pos_spec, scale):
+        x = x.contiguous()
+        h = conv_fwd_raw(conv_spec, x, _xf(L.XF_LRELU))
+        if gb is not None:
+            gb = gb.contiguous()
+            xf2 = _xf(L.XF_FILM_LRELU, aux=gb)
+        else:
+            xf2 = _xf(L.XF_LRELU)
+        out = conv_fwd_raw(pos_spec, h, xf2, res=x, add=acc, out_scale=scale)
+        ctx.cs, ctx.ps, ctx.scale = conv_spec, pos_spec, scale
+        ctx.has_gb, ctx.has_acc = gb is not None, acc is not None
+        ctx.save_for_backward(x, h, gb)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        x, h, gb = ctx.saved_tensors
+        d_out = d_out.contiguous()
+        s = ctx.scale
+        T = x.shape[2]
+        dy_xf = _xf(scale=s)
+        if ctx.has_gb:
+            dgb = torch.empty_like(gb)
+            dh = conv_dgrad_raw(ctx.ps, d_out, dy_xf, T, L.DG_FILM, x_in=h, gb=gb, dgb=dgb)
+            conv_wgrad_raw(ctx.ps, h, _xf(L.XF_FILM_LRELU, aux=gb), d_out, dy_xf)
+        else:
+            dgb = None
+            dh = conv_dgrad_raw(ctx.ps, d_out, dy_xf, T, L.DG_MASK_LRELU, x_in=h)
+            conv_wgrad_raw(ctx.ps, h, _xf(L.XF_LRELU), d_out, dy_xf)
+        conv_wgrad_raw(ctx.cs, x, _xf(L.XF_LRELU), dh, _xf())
+        dx = conv_dgrad_raw(ctx.cs, dh, _xf(), T, L.DG_MASK_LRELU, x_in=x, add=d_out, add_scale=s)
+        return dx, dgb, (d_out if ctx.has_acc else None), None, None, None, None
+
+
+def film_block(x, gb, acc, conv_spec, pos_spec, scale):
+    return FilmBlockFn.apply(x, gb, acc, _token(conv_spec, pos_spec), conv_spec, pos_spec, scale)
+
+
+# ------------------------------------------------------------------------------- small ops
+class L2NormFn(Function):
+    @staticmethod
+    def forward(ctx, x):
+        x = x.contiguous()
+        B, Cc, T = x.shape
+        y = torch.empty_like(x)
+        inv = torch.empty((B, T), dtype=torch.float32, device=x.device)
+        L.check(L.lib().tdvc_l2norm_fwd(x.data_ptr(), y.data_ptr(), inv.data_ptr(), B, Cc, T, 1e-12, _stream(x)))
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        y, inv = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, Cc, T = y.shape
+        dx = torch.empty_like(y)
+        L.check(L.lib().tdvc_l2norm_bwd(y.data_ptr(), inv.data_ptr(), dy.data_ptr(), dx.data_ptr(), B, Cc, T, _stream(y)))
+        return dx
+
+
+class GatherChFn(Function):
+    @staticmethod
+    def forward(ctx, x, label):
+        x = x.contiguous()
+        B, Cc, T = x.shape
+        y = torch.empty((B, 1, T), dtype=torch.float32, device=x.device)
+        L.check(L.lib().tdvc_gather_ch_fwd(x.data_ptr(), label.data_ptr(), y.data_ptr(), B, Cc, T, _stream(x)))
+        ctx.save_for_backward(label)
+        ctx.C = Cc
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (label,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, _, T = dy.shape
+        dx = torch.empty((B, ctx.C, T), dtype=torch.float32, device=dy.device)
+        L.check(L.lib().tdvc_gather_ch_bwd(dy.data_ptr(), label.data_ptr(), dx.data_ptr(), B, ctx.C, T, _stream(dy)))
+        return dx, None
+
+
+class ConcatCondFn(Function):
+    """c = cat([emb.unsqueeze(2).repeat(1,1,T), exc], dim=1) (model/generator.py:387-399)."""
+
+    @staticmethod
+    def forward(ctx, emb, exc):
+        emb, exc = emb.contiguous(), exc.contiguous()
+        B, Ce = emb.shape
+        _, Cx, T = exc.shape
+        c = torch.empty((B, Ce + Cx, T), dtype=torch.float32, device=exc.device)
+        L.check(L.lib().tdvc_concat_cond(emb.data_ptr(), exc.data_ptr(), c.data_ptr(), B, Ce, Cx, T, _stream(exc)))
+        ctx.dims = (B, Ce, Cx, T)
+        return c
+
+    @staticmethod
+    def backward(ctx, dc):
+        B, Ce, Cx, T = ctx.dims
+        dc = dc.contiguous()
+        demb = torch.empty((B, Ce), dtype=torch.float32, device=dc.device)
+        dexc = torch.empty((B, Cx, T), dtype=torch.float32, device=dc.device)
+        L.check(L.lib().tdvc_concat_cond_bwd(dc.data_ptr(), demb.data_ptr(), dexc.data_ptr(), B, Ce, Cx, T, 0, _stream(dc)))
+        return demb, dexc
+
+
+class CinFn(Function):
+    """(1+gamma) * InstanceNorm(x) + beta, gb = [gamma; beta] as [B,2C,1] or [B,2C,T]."""
+
+    @staticmethod
+    def forward(ctx, x, gb, eps):
+        x, gb = x.contiguous(), gb.contiguous()
+        B, Cc, T = x.shape
+        Tg = gb.shape[2]
+        y = torch.empty_like(x)
+        mean = torch.empty((B, Cc), dtype=torch.float32, device=x.device)
+        rstd = torch.empty_like(mean)
+        L.check(L.lib().tdvc_cin_fwd(x.data_ptr(), gb.data_ptr(), y.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                     B, Cc, T, Tg, eps, _stream(x)))
+        ctx.save_for_backward(x, gb, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gb, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        B, Cc, T = x.shape
+        dx, dgb = torch.empty_like(x), torch.empty_like(gb)
+        L.check(L.lib().tdvc_cin_bwd(x.data_ptr(), gb.data_ptr(), dy.data_ptr(), mean.data_ptr(), rstd.data_ptr(),
+                                     dx.data_ptr(), dgb.data_ptr(), B, Cc, T, gb.shape[2], _stream(x)))
+        return dx, dgb, None
+
+
+def axpby(a, b, alpha, beta):
+    y = torch.empty_like(a)
+    L.check(L.lib().tdvc_axpby(a.data_ptr(), b.data_ptr() if b is not None else None, y.data_ptr(), alpha, beta,
+                               a.numel(), _stream(a)))
+    return y

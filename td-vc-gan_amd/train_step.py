@@ -1,0 +1,149 @@
+"""One TD-VC-GAN training iteration (D-step + G-step, both AdamW updates) on the HIP path.
+
+Mirrors the loop body of the reference's train.py:209-521 (D-step :259-316, G-step :320-510,
+loss assembly :477-482, optimizers :188-189) for the configuration space of the shipped YAMLs,
+minus the CREPE-backed F0 term (:429-470, torchcrepe unavailable: SURVEY §8c) and minus work
+that reaches no parameter update:
+  Q3  the D-step's generator forward runs without a graph (the reference back-propagates into G
+      through the sub-scale heads and then discards those gradients);
+  Q4  the G-step reuses the D-step's generator forward (identical inputs and weights) instead of
+      recomputing it — bit-identical by construction, `reuse_fake=False` recomputes like the reference;
+  Q5  discriminator weight gradients are not computed in the G-step;
+  Q6  D(real) feature maps of the G-step run forward-only.
+Scalar names follow the reference's tensorboard tags (D_loss_adv_real, G_loss_idt_feat, ...).
+"""
+from dataclasses import dataclass
+
+import torch
+
+from . import losses as LS
+from .arena import FlatAdamW
+
+
+@dataclass
+class StepConfig:
+    no_conv: bool = False
+    lambda_rec: float = 0.0
+    lambda_idt: float = 5.0
+    lambda_feat: float = 2.0
+    lambda_spec: float = 5.0
+    lambda_cont_emb: float = 10.0
+    lambda_corrupted: float = 1.0
+    lambda_f0: float = 0.0
+    lr_g: float = 1e-4
+    lr_d: float = 1e-4
+    betas: tuple = (0.8, 0.99)
+    eps: float = 1e-8
+    weight_decay: float = 1e-2
+    n_neg: int = 100
+    fft_sizes: tuple = (2048, 1024, 512)
+
+    @staticmethod
+    def from_hparams(train: dict) -> 'StepConfig':
+        g = train.get
+        return StepConfig(no_conv=bool(g('no_conv', False)), lambda_rec=float(g('lambda_rec', 0)),
+                          lambda_idt=float(g('lambda_idt', 0)), lambda_feat=float(g('lambda_feat', 0)),
+                          lambda_spec=float(g('lambda_spec', 0)), lambda_cont_emb=float(g('lambda_cont_emb', 0)),
+                          lambda_corrupted=float(g('lambda_corrupted', 0)), lambda_f0=float(g('lambda_f0', 0)),
+                          lr_g=float(g('lr_g', 1e-4)), lr_d=float(g('lr_d', 1e-4)),
+                          betas=tuple(g('adam_beta', (0.8, 0.99))))
+
+
+class TrainStep:
+    def __init__(self, G, D, cfg: StepConfig, device, reuse_fake=True, grad_sync=None):
+        if cfg.lambda_rec > 0:
+            raise NotImplementedError('lambda_rec > 0 (cycle reconstruction branch, train.py:344-361) is not built yet')
+        self.G, self.D, self.cfg, self.device = G, D, cfg, torch.device(device)
+        self.reuse_fake = reuse_fake
+        self.grad_sync = grad_sync            # parallel.GradSync or None
+        ga, da = G.ensure_arena(self.device), D.ensure_arena(self.device)
+        self.opt_g = FlatAdamW(ga, cfg.lr_g, cfg.betas, cfg.eps, cfg.weight_decay)
+        self.opt_d = FlatAdamW(da, cfg.lr_d, cfg.betas, cfg.eps, cfg.weight_decay)
+        G.weights_frozen(True); D.weights_frozen(True)     # effective weights are rebuilt right after each update
+        ga.materialize(); da.materialize()
+
+    # -------------------------------------------------------------------------------------------
+    def _gen(self, batch, c, c_var):
+        y, subs = self.G(batch['signal_real'], c, c_var=c_var, out_subsample=True)
+        return y, subs, self.G.content_embedding
+
+    def d_step(self, batch, log):
+        G, D = self.G, self.D
+        if self.reuse_fake:
+            fake, fake_subs, emb_real = self._gen(batch, batch['c_tgt'], batch['c_f0_conv'])
+            self._fake = (fake, fake_subs, emb_real)
+        else:
+            with torch.no_grad():
+                fake, fake_subs, _ = self._gen(batch, batch['c_tgt'], batch['c_f0_conv'])
+        real = batch['signal_real']
+        self._real_subs = D.get_subsamples(real)
+        out_real, _ = D(real, batch['label_src'], self._real_subs)
+        out_fake, _ = D(fake.detach(), batch['label_tgt'], [s.detach() for s in fake_subs])
+        l_real = LS.lsgan_loss(out_real, 1.0)
+        l_fake = LS.lsgan_loss(out_fake, 0.0)
+        d_loss = l_real + l_fake
+        self.opt_d.zero_grad()
+        d_loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync.all_reduce(D.arena)
+        self.opt_d.step(grad_scale=1.0 if self.grad_sync is None else self.grad_sync.scale)
+        D.arena.materialize()
+        log.update(D_loss_adv_real=l_real.detach(), D_loss_adv_fake=l_fake.detach(), D_loss=d_loss.detach())
+
+    def g_step(self, batch, log, idx_x=None, idx_y=None):
+        G, D, c = self.G, self.D, self.cfg
+        real = batch['signal_real']
+        D.arena.wgrad_enabled = False                     # Q5
+        try:
+            if self.reuse_fake:
+                fake, fake_subs, emb_real = self._fake
+                self._fake = None
+            else:
+                fake, fake_subs, emb_real = self._gen(batch, batch['c_tgt'], batch['c_f0_conv'])
+            out_fake, _ = D(fake, batch['label_tgt'], fake_subs)
+            adv = LS.lsgan_loss(out_fake, 1.0)
+            total = adv
+            log['G_loss_adv_fake'] = adv.detach()
+            feats_real = None
+            if (c.lambda_rec > 0 or c.lambda_idt > 0) and c.lambda_feat > 0:
+                with torch.no_grad():                      # Q6
+                    _, feats_real = D(real, batch['label_src'], self._real_subs)
+            if c.lambda_idt > 0:
+                if c.no_conv:
+                    idt, idt_subs = fake, fake_subs
+                else:
+                    idt, idt_subs, _ = self._gen(batch, batch['c_src'], batch['c_f0_src'])
+                l_idt = None
+                if c.lambda_feat > 0:
+                    _, feats_idt = D(idt, batch['label_src'], idt_subs)
+                    l_feat = LS.multiscale_feat_loss(feats_idt, feats_real, norm_p=1)
+                    log['G_loss_idt_feat'] = l_feat.detach()
+                    l_idt = c.lambda_feat * l_feat
+                if c.lambda_spec > 0:
+                    l_spec = LS.multiscale_spec_loss(idt, real, list(c.fft_sizes))
+                    log['G_loss_idt_spec'] = l_spec.detach()
+                    l_idt = c.lambda_spec * l_spec if l_idt is None else l_idt + c.lambda_spec * l_spec
+                if l_idt is not None:
+                    log['G_loss_idt'] = l_idt.detach()
+                    total = total + c.lambda_idt * l_idt
+            if c.lambda_cont_emb > 0 and c.lambda_corrupted:
+                emb_cor = G.encoder(batch['signal_corrupted'])
+                l_con = LS.contrastive_loss(emb_real, emb_cor, num_negatives=c.n_neg, temp=0.1, idx_x=idx_x, idx_y=idx_y)
+                log['G_loss_cont_emb'] = l_con.detach()
+                total = total + c.lambda_cont_emb * l_con
+            self.opt_g.zero_grad()
+            total.backward()
+        finally:
+            D.arena.wgrad_enabled = True
+        if self.grad_sync is not None:
+            self.grad_sync.all_reduce(G.arena)
+        self.opt_g.step(grad_scale=1.0 if self.grad_sync is None else self.grad_sync.scale)
+        G.arena.materialize()
+        log['G_loss'] = total.detach()
+
+    def run(self, batch, idx_x=None, idx_y=None):
+        """One iteration. Returns {tag: 1-element device tensor}; no host synchronisation inside."""
+        log = {}
+        self.d_step(batch, log)
+        self.g_step(batch, log, idx_x, idx_y)
+        return log

@@ -1,0 +1,162 @@
+"""GPU parity of the conv C-ABI (tdvc_conv_fwd / dgrad / wgrad) against torch CPU float64 autograd,
+for every conv shape class on the path, on both the MFMA and the scalar kernels."""
+import importlib
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+from conftest import rel_l2
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5   # fp32 accumulation vs float64 reference, rel-L2 per tensor
+
+
+def _mods():
+    pkg = importlib.import_module('td-vc-gan_amd')
+    return pkg.ops, pkg._lib, pkg.arena
+
+
+# (name, cin, cout, k, stride, pad, dil, groups, reflect, transposed, T, pre, post)
+CASES = [
+    ('dil_c16_k3_d1', 16, 16, 3, 1, 1, 1, 1, True, False, 1000, 1, 0),
+    ('dil_c16_k11_d5', 16, 16, 11, 1, 25, 5, 1, True, False, 700, 1, 0),
+    ('dil_c32_k7_d3', 32, 32, 7, 1, 9, 3, 1, True, False, 520, 1, 0),
+    ('dil_c64_k3_d5', 64, 64, 3, 1, 5, 5, 1, True, False, 300, 1, 0),
+    ('dil_c128_k11_d1', 128, 128, 11, 1, 5, 1, 1, True, False, 100, 1, 0),
+    ('dil_c256_k11_d5_T50', 256, 256, 11, 1, 25, 5, 1, True, False, 50, 1, 0),
+    ('pw_c64', 64, 64, 1, 1, 0, 1, 1, False, False, 333, 1, 0),
+    ('pw_c16', 16, 16, 1, 1, 0, 1, 1, False, False, 1000, 1, 0),
+    ('cond0_136', 136, 136, 3, 1, 1, 1, 1, False, False, 260, 0, 0),
+    ('cond2_136_32', 136, 32, 3, 1, 1, 1, 1, False, False, 260, 1, 0),
+    ('in_1_16_k7', 1, 16, 7, 1, 3, 1, 1, True, False, 900, 0, 0),
+    ('head_16_1_tanh', 16, 1, 7, 1, 3, 1, 1, True, False, 900, 1, 2),
+    ('d0_1_16_k15_lrelu', 1, 16, 15, 1, 7, 1, 1, True, False, 800, 0, 1),
+    ('k7_256_128_T50', 256, 128, 7, 1, 3, 1, 1, False, False, 50, 1, 0),
+    ('d5_256_256_k5_lrelu', 256, 256, 5, 1, 2, 1, 1, False, False, 63, 0, 1),
+    ('dout_256_16_k3', 256, 16, 3, 1, 1, 1, 1, False, False, 63, 0, 0),
+    ('exc_8_8_k5', 8, 8, 5, 1, 2, 1, 1, False, False, 500, 1, 0),
+    ('down_16_32_s2', 16, 32, 4, 2, 1, 1, 1, False, False, 1000, 1, 0),
+    ('down_64_128_s8', 64, 128, 16, 8, 4, 1, 1, False, False, 800, 1, 0),
+    ('down_128_256_s10', 128, 256, 20, 10, 5, 1, 1, False, False, 500, 1, 0),
+    ('exc_down_8_8_s8', 8, 8, 16, 8, 4, 1, 1, False, False, 640, 0, 0),
+    ('grp_16_64_k41_s4', 16, 64, 41, 4, 20, 1, 4, False, False, 1000, 0, 1),
+    ('grp_64_256_k41_s4', 64, 256, 41, 4, 20, 1, 16, False, False, 500, 0, 1),
+    ('grp_64_64_k41_s4_g16', 64, 64, 41, 4, 20, 1, 16, False, False, 250, 0, 1),
+    ('up_256_128_s10', 256, 128, 20, 10, 5, 1, 1, False, True, 50, 1, 0),
+    ('up_128_64_s8', 128, 64, 16, 8, 4, 1, 1, False, True, 100, 1, 0),
+    ('up_32_16_s2', 32, 16, 4, 2, 1, 1, 1, False, True, 700, 1, 0),
+    ('fir_dw8_k33_s2', 8, 8, 33, 2, 16, 1, 8, False, False, 1000, 0, 0),
+    ('fir_dw8_k129_s8', 8, 8, 129, 8, 64, 1, 8, False, False, 1024, 0, 0),
+    ('fir_1_k129_s2', 1, 1, 129, 2, 64, 1, 1, False, False, 1000, 0, 0),
+    ('stft_like_1_40_k64_s16', 1, 40, 64, 16, 0, 1, 1, False, False, 640, 0, 0),
+    ('linear_16_128_T1', 16, 128, 1, 1, 0, 1, 1, False, False, 1, 0, 0),
+]
+
+
+def _torch_ref(x, w, b, add, c):
+    (_, cin, cout, k, s, p, d, g, reflect, transposed, T, pre, post) = c
+    h = F.leaky_relu(x, 0.2) if pre else x
+    if transposed:
+        y = F.conv_transpose1d(h, w, b, stride=s, padding=p)
+    else:
+        if reflect and p > 0:
+            h = F.pad(h, (p, p), mode='reflect')
+            y = F.conv1d(h, w, b, stride=s, dilation=d, groups=g)
+        else:
+            y = F.conv1d(h, w, b, stride=s, padding=p, dilation=d, groups=g)
+    if post == 1:
+        y = F.leaky_relu(y, 0.2)
+    elif post == 2:
+        y = torch.tanh(y)
+    if add is not None:
+        y = y + add
+    return y
+
+
+@pytest.mark.parametrize('generic', [0, 1], ids=['mfma', 'scalar'])
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+def test_conv_fwd_bwd(case, generic, dev):
+    ops, L, arena = _mods()
+    (name, cin, cout, k, s, p, d, g, reflect, transposed, T, pre, post) = case
+    torch.manual_seed(sum(map(ord, name)))
+    B = 3
+    wshape = (cin, cout // g, k) if transposed else (cout, cin // g, k)
+    x = torch.randn(B, cin, T, dtype=torch.float64)
+    w = torch.randn(wshape, dtype=torch.float64) / (wshape[1] * k) ** 0.5
+    b = torch.randn(cout, dtype=torch.float64) * 0.1
+    spec = ops.ConvSpec(cin, cout, k, s, p, d, g, reflect, transposed)
+    tout = spec.tout(T)
+    add = torch.randn(B, cout, tout, dtype=torch.float64) if name.startswith('exc_8') else None
+    xr, wr, br = x.clone().requires_grad_(True), w.clone().requires_grad_(True), b.clone().requires_grad_(True)
+    yr = _torch_ref(xr, wr, br, add, case)
+    cot = torch.randn_like(yr)
+    (yr * cot).sum().backward()
+
+    wd, bd = w.float().to(dev).contiguous(), b.float().to(dev).contiguous()
+    dw, db = torch.zeros_like(wd), torch.zeros_like(bd)
+    spec.slot = arena.ConvSlot(wd.data_ptr(), bd.data_ptr(), dw.data_ptr(), db.data_ptr(), True, None)
+    L.lib().tdvc_set_force_generic(generic)
+    try:
+        xd = x.float().to(dev).requires_grad_(True)
+        addd = add.float().to(dev) if add is not None else None
+        y = ops.ConvFn.apply(xd, addd, None, spec, pre, post)
+        assert y.shape == yr.shape
+        e_y = rel_l2(y, yr)
+        y.backward(cot.float().to(dev))
+        torch.cuda.synchronize()
+        e_dx, e_dw, e_db = rel_l2(xd.grad, xr.grad), rel_l2(dw, wr.grad), rel_l2(db, br.grad)
+    finally:
+        L.lib().tdvc_set_force_generic(0)
+    assert e_y < TOL and e_dx < TOL and e_dw < TOL and e_db < TOL, dict(y=e_y, dx=e_dx, dw=e_dw, db=e_db)
+
+
+@pytest.mark.parametrize('cfg', [(16, 3, 1, 900, True, True), (32, 7, 3, 400, True, False), (64, 11, 5, 260, False, True),
+                                 (128, 3, 1, 100, True, True), (256, 11, 5, 50, False, False)],
+                         ids=['c16k3', 'c32k7d3', 'c64k11d5_enc', 'c128k3', 'c256k11d5_enc'])
+def test_film_block(cfg, dev):
+    """Fused FiLM residual block (model/generator.py:96-111) incl. MRF running-mean epilogue."""
+    ops, L, arena = _mods()
+    C, k, d, T, cond, with_acc = cfg
+    torch.manual_seed(C + k)
+    B, pad, scale = 2, (k * d - d) // 2, 1.0 / 3.0
+    x = torch.randn(B, C, T, dtype=torch.float64)
+    gb = torch.randn(B, 2 * C, T, dtype=torch.float64) * 0.5 if cond else None
+    acc = torch.randn(B, C, T, dtype=torch.float64) if with_acc else None
+    w1 = torch.randn(C, C, k, dtype=torch.float64) / (C * k) ** 0.5
+    b1 = torch.randn(C, dtype=torch.float64) * 0.1
+    w2 = torch.randn(C, C, 1, dtype=torch.float64) / C ** 0.5
+    b2 = torch.randn(C, dtype=torch.float64) * 0.1
+    leaves = [t.clone().requires_grad_(True) for t in (x, w1, b1, w2, b2)] + \
+             [gb.clone().requires_grad_(True) if cond else None, acc.clone().requires_grad_(True) if with_acc else None]
+    xr, w1r, b1r, w2r, b2r, gbr, accr = leaves
+    h = F.conv1d(F.pad(F.leaky_relu(xr, 0.2), (pad, pad), mode='reflect'), w1r, b1r, dilation=d)
+    if cond:
+        ga, be = gbr.chunk(2, dim=1)
+        h = h * (1 + ga) + be
+    out = scale * (F.conv1d(F.leaky_relu(h, 0.2), w2r, b2r) + xr)
+    if with_acc:
+        out = out + accr
+    cot = torch.randn_like(out)
+    (out * cot).sum().backward()
+
+    f = lambda t: t.float().to(dev).contiguous()
+    dts = {n: f(t) for n, t in dict(w1=w1, b1=b1, w2=w2, b2=b2).items()}
+    grads = {n: torch.zeros_like(t) for n, t in dts.items()}
+    cs = ops.ConvSpec(C, C, k, 1, pad, d, 1, True)
+    ps = ops.ConvSpec(C, C, 1)
+    cs.slot = arena.ConvSlot(dts['w1'].data_ptr(), dts['b1'].data_ptr(), grads['w1'].data_ptr(), grads['b1'].data_ptr(), True, None)
+    ps.slot = arena.ConvSlot(dts['w2'].data_ptr(), dts['b2'].data_ptr(), grads['w2'].data_ptr(), grads['b2'].data_ptr(), True, None)
+    xd = f(x).requires_grad_(True)
+    gbd = f(gb).requires_grad_(True) if cond else None
+    accd = f(acc).requires_grad_(True) if with_acc else None
+    y = ops.FilmBlockFn.apply(xd, gbd, accd, None, cs, ps, scale)
+    y.backward(f(cot))
+    torch.cuda.synchronize()
+    errs = dict(y=rel_l2(y, out), dx=rel_l2(xd.grad, xr.grad), dw1=rel_l2(grads['w1'], w1r.grad), db1=rel_l2(grads['b1'], b1r.grad),
+                dw2=rel_l2(grads['w2'], w2r.grad), db2=rel_l2(grads['b2'], b2r.grad))
+    if cond:
+        errs['dgb'] = rel_l2(gbd.grad, gbr.grad)
+    if with_acc:
+        errs['dacc'] = rel_l2(accd.grad, accr.grad)
+    assert max(errs.values()) < TOL, errs

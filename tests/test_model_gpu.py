@@ -1,0 +1,147 @@
+"""GPU parity of the drop-in Generator / Discriminator / train step against (a) the committed golden
+fixtures generated from the reference itself and (b) the CPU oracle on the same seeded inputs.
+Tolerance: 1e-3 relative (north_star), per-tensor rel-L2 for gradients (SURVEY §7 hard part (f))."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from common import GOLDEN, build_models, filled_sd, pkg, rel_l2, to_dev
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+@pytest.fixture(scope='module')
+def models(dev):
+    return build_models(dev)
+
+
+@pytest.mark.parametrize('tag,seed', [('B2_T8960', 7), ('B2_T16000', 1234)])
+def test_generator_forward_backward_vs_golden(models, dev, tag, seed):
+    G, _ = models
+    T = int(tag.split('_T')[1])
+    bt = to_dev(pkg().synth.make_batch(2, T, seed=seed), dev)
+    gold = np.load(os.path.join(GOLDEN, f'gen_fwd_{tag}.npz'))
+    G.arena.zero_grad()
+    y, subs = G(bt['signal_real'], bt['c_tgt'], c_var=bt['c_f0_conv'], out_subsample=True)
+    emb = G.content_embedding
+    errs = dict(y=rel_l2(y, torch.from_numpy(gold['y'])), sub4=rel_l2(subs[0], torch.from_numpy(gold['sub4'])),
+                sub2=rel_l2(subs[1], torch.from_numpy(gold['sub2'])), emb=rel_l2(emb, torch.from_numpy(gold['emb'])))
+    assert max(errs.values()) < TOL, errs
+    # same cotangents as oracle/make_golden.py
+    rs = np.random.RandomState(99)
+    outs = (y, subs[0], subs[1], emb)
+    cot = [torch.from_numpy(rs.randn(*t.shape).astype(np.float32)).to(dev) for t in outs]
+    loss = sum((t * c).mean() for t, c in zip(outs, cot))
+    loss.backward()
+    torch.cuda.synchronize()
+    gg = json.load(open(os.path.join(GOLDEN, f'gen_grad_{tag}.json')))
+    assert abs(float(loss) - gg['loss']) <= TOL * max(1e-3, abs(gg['loss']))
+    bad = {}
+    for k, p in G.named_parameters():
+        n_ref = gg['norms'][k]
+        if n_ref < 0:
+            assert p.grad is None, f'{k}: reference leaves grad None (Q7)'
+            continue
+        assert p.grad is not None, k
+        n = float(p.grad.double().norm())
+        idx, vals = gg['samples'][k]
+        samp = p.grad.reshape(-1)[torch.tensor(idx, device=dev)].double().cpu()
+        e_norm = abs(n - n_ref) / (n_ref + 1e-30)
+        e_samp = float((samp - torch.tensor(vals)).norm()) / (n_ref / max(1.0, p.numel() ** 0.5) * 2 + 1e-30)
+        if e_norm > TOL or e_samp > 0.05:
+            bad[k] = (e_norm, e_samp)
+    assert not bad, dict(list(bad.items())[:8])
+
+
+def test_generator_grads_vs_oracle_full(models, dev):
+    """Every gradient element of every parameter against the CPU oracle (rel-L2 per tensor)."""
+    from oracle import model as OM
+    G, _ = models
+    bt_cpu = pkg().synth.make_batch(2, 8960, seed=11)
+    bt = to_dev(bt_cpu, dev)
+    sg = {k: v.clone().requires_grad_(True) for k, v in filled_sd('G').items()}
+    oy, osubs, oemb = OM.generator(sg, bt_cpu['signal_real'], bt_cpu['c_tgt'], bt_cpu['c_f0_conv'])
+    rs = np.random.RandomState(5)
+    cot = [torch.from_numpy(rs.randn(*t.shape).astype(np.float32)) for t in (oy, osubs[0], osubs[1], oemb)]
+    sum((t * c).mean() for t, c in zip((oy, osubs[0], osubs[1], oemb), cot)).backward()
+    G.arena.zero_grad()
+    y, subs = G(bt['signal_real'], bt['c_tgt'], c_var=bt['c_f0_conv'], out_subsample=True)
+    outs = (y, subs[0], subs[1], G.content_embedding)
+    sum((t * c.to(dev)).mean() for t, c in zip(outs, cot)).backward()
+    torch.cuda.synchronize()
+    errs = {k: rel_l2(p.grad, sg[k].grad) for k, p in G.named_parameters() if p.grad is not None}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    assert worst[0][1] < TOL, worst
+    assert rel_l2(y, oy) < TOL
+
+
+@pytest.mark.parametrize('tag,seed', [('B2_T8960', 7), ('B2_T16000', 1234)])
+def test_discriminator_vs_golden(models, dev, tag, seed):
+    _, D = models
+    LS = pkg().losses
+    T = int(tag.split('_T')[1])
+    bt = to_dev(pkg().synth.make_batch(2, T, seed=seed), dev)
+    gold = np.load(os.path.join(GOLDEN, f'disc_{tag}.npz'))
+    gj = json.load(open(os.path.join(GOLDEN, f'disc_{tag}.json')))
+    gen = np.load(os.path.join(GOLDEN, f'gen_fwd_{tag}.npz'))
+    fake = torch.from_numpy(gen['y']).to(dev)
+    fsubs = [torch.from_numpy(gen['sub4']).to(dev), torch.from_numpy(gen['sub2']).to(dev)]
+    rsubs = D.get_subsamples(bt['signal_real'])
+    for i, s in enumerate(rsubs):
+        assert rel_l2(s, torch.from_numpy(gold[f'sub_real_{i}'])) < TOL
+    D.arena.zero_grad()
+    o_r, f_r = D(bt['signal_real'], bt['label_src'], rsubs)
+    o_f, f_f = D(fake, bt['label_tgt'], fsubs)
+    for i in range(5):
+        assert rel_l2(o_r[i], torch.from_numpy(gold[f'out_real_{i}'])) < TOL, ('real', i)
+        assert rel_l2(o_f[i], torch.from_numpy(gold[f'out_fake_{i}'])) < TOL, ('fake', i)
+    for fl, ref in ((f_r, gj['feat_stats_real']), (f_f, gj['feat_stats_fake'])):
+        for p_, (maps, stats) in enumerate(zip(fl, ref)):
+            for m, st in zip(maps, stats):
+                md = m.double()
+                got = [float(md.mean()), float(md.abs().mean()), float(md.std())]
+                assert abs(got[1] - st[1]) <= TOL * abs(st[1]) and abs(got[2] - st[2]) <= TOL * abs(st[2]), (p_, got, st)
+    loss = LS.lsgan_loss(o_r, 1.0) + LS.lsgan_loss(o_f, 0.0)
+    assert abs(float(loss) - gj['loss']) <= TOL * abs(gj['loss'])
+    loss.backward()
+    torch.cuda.synchronize()
+    bad = {}
+    for k, p in D.named_parameters():
+        n_ref = gj['norms'][k]
+        e = abs(float(p.grad.double().norm()) - n_ref) / (n_ref + 1e-30)
+        if e > TOL:
+            bad[k] = e
+    assert not bad, bad
+
+
+@pytest.mark.parametrize('cfg_name,T', [('conv_enc-stage1', 8960), ('conv_enc-stage2_1', 8960), ('conv_enc-stage1', 16000)])
+def test_train_step_vs_golden(dev, cfg_name, T):
+    """Full iteration(s): every logged loss scalar vs the fixture produced by the reference's own modules
+    + torch.optim.AdamW; post-update parameters vs the fixture checksums."""
+    P = pkg()
+    gold = json.load(open(os.path.join(GOLDEN, f'step_{cfg_name}_T{T}.json')))
+    hp = P.hparams.HParam(os.path.join(os.path.dirname(GOLDEN), '..', 'config', f'{cfg_name}.yaml'))
+    cfg = P.train_step.StepConfig.from_hparams(hp.train)
+    G, D = build_models(dev)
+    ts = P.train_step.TrainStep(G, D, cfg, dev)
+    bt = to_dev(P.synth.make_batch(gold['B'], T, seed=1234, conversion=not cfg.no_conv), dev)
+    Tn = T // 320
+    for it, ref in enumerate(gold['losses']):
+        ix = P.synth.contrastive_indices(gold['B'], Tn, cfg.n_neg, seed=100 + 2 * it)
+        iy = P.synth.contrastive_indices(gold['B'], Tn, cfg.n_neg, seed=101 + 2 * it)
+        log = ts.run(bt, ix, iy)
+        torch.cuda.synchronize()
+        errs = {k: abs(float(log[k]) - v) / (abs(v) + 1e-12) for k, v in ref.items()}
+        assert max(errs.values()) < TOL, (it, errs)
+    for name, model, key in (('G', G, 'params_G'), ('D', D, 'params_D')):
+        bad = {}
+        for k, v in model.state_dict().items():
+            s, a = gold[key][k]
+            got_a = float(v.double().abs().sum())
+            if abs(got_a - a) > TOL * (abs(a) + 1e-12):
+                bad[k] = (got_a, a)
+        assert not bad, (name, dict(list(bad.items())[:5]))
