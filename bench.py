@@ -55,11 +55,27 @@ def time_conv_kernel(pkg, dev, B, cin, cout, k, dil, T, iters=50):
     return ms, alg_bytes, flops
 
 
+def usable_cores():
+    """CPUs this process may actually run on (the GPU box exposes more logical CPUs than its cgroup share)."""
+    try:
+        n = len(os.sched_getaffinity(0))
+    except AttributeError:
+        n = os.cpu_count() or 1
+    try:  # cgroup v2 quota
+        q, per = open('/sys/fs/cgroup/cpu.max').read().split()
+        if q != 'max':
+            n = min(n, max(1, int(int(q) / int(per))))
+    except Exception:
+        pass
+    return max(1, min(n, 32))
+
+
 def cpu_baseline(pkg, cfg_train, iters=2):
     """CPU oracle timed on this host: B=2 x 1 s, 1 warm-up + `iters` timed iterations (~10-30 s)."""
     from common import filled_sd
     from oracle import step as OS
-    torch.set_num_threads(os.cpu_count())
+    cores = usable_cores()
+    torch.set_num_threads(cores)
     cfg = OS.StepConfig.from_hparams(cfg_train)
     st = OS.TrainStep(filled_sd('G'), filled_sd('D'), cfg)
     B, T = 2, SR
@@ -70,7 +86,7 @@ def cpu_baseline(pkg, cfg_train, iters=2):
     for _ in range(iters):
         t0 = time.perf_counter(); st.run(bt, ix, iy); ts.append(time.perf_counter() - t0)
     t = sorted(ts)[len(ts) // 2]
-    return dict(value=B * T / SR / t, unit='audio-seconds/sec', cores=os.cpu_count(), kind='port',
+    return dict(value=B * T / SR / t, unit='audio-seconds/sec', cores=cores, kind='port',
                 sample=f'conv_enc-stage1 full D+G iteration, B={B} x 1 s, median of {iters} after 1 warm-up; '
                        f'CPU oracle (torch {torch.__version__} CPU, {torch.get_num_threads()} threads)')
 
@@ -116,6 +132,8 @@ def main():
     for _ in range(args.warmup):
         log = step()
     torch.cuda.synchronize()
+    if rank == 0:
+        print(f'[bench] warm-up done ({args.warmup} steps)', file=sys.stderr, flush=True)
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
@@ -132,6 +150,8 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     g_loss = float(log['G_loss'])
+    if rank == 0:
+        print(f'[bench] timed region: {dt / args.steps * 1e3:.2f} ms/step', file=sys.stderr, flush=True)
     if not (g_loss == g_loss):
         raise SystemExit('non-finite loss in the timed region')
 
