@@ -57,6 +57,11 @@ typedef struct {
   int32_t Tin, Tout;
   int32_t K, stride, dilation, pad, groups;
   int32_t reflect;       /* 1: padding_mode='reflect' (stride 1 only), 0: zeros */
+  /* Input-channel window of the weight tensor (groups == 1, kind == TDVC_CONV): the weight is
+   * [Cout][w_cin][K] and this call uses input channels [w_cin_off, w_cin_off + Cin). 0/0 = whole tensor.
+   * Lets FiLM's cond_var.0 (model/generator.py:88) split into its time-constant speaker-embedding part
+   * (128 channels, evaluated on a length-3 signal) and its 8-channel excitation part (SURVEY §2.2 reduction 2). */
+  int32_t w_cin, w_cin_off;
 } tdvc_conv_desc;
 
 typedef struct {
@@ -69,6 +74,7 @@ typedef struct {
   float out_scale;                   /* y = out_scale * post(conv+bias+res) + (add ? add : 0) */
   const float* add; int64_t add_bs;  /* optional running sum (MRF mean, model/generator.py:192-193) */
   float* y; int64_t y_bs;
+  const float* bias3;                /* optional [B][Cout][3]: per-sample bias for t==0 / interior / t==Tout-1 */
 } tdvc_conv_fwd_args;
 
 typedef struct {
@@ -124,6 +130,8 @@ int tdvc_gather_ch_fwd(const float* x, const int64_t* label, float* y, int B, in
 int tdvc_gather_ch_bwd(const float* dy, const int64_t* label, float* dx, int B, int C, int T, void* stream);
 int tdvc_concat_cond(const float* emb, const float* exc, float* c, int B, int Ce, int Cx, int T, void* stream);   /* cat([emb.repeat(T), exc]), model/generator.py:387-399 */
 int tdvc_concat_cond_bwd(const float* dc, float* demb, float* dexc, int B, int Ce, int Cx, int T, int accumulate_emb, void* stream);
+/* out[b][c][0..2] = d[b][c][0], sum_{t=1..T-2} d[b][c][t], d[b][c][T-1]  (adjoint of the bias3 broadcast) */
+int tdvc_edge_sum3(const float* d, float* out, int B, int C, int T, void* stream);
 int tdvc_axpby(const float* a, const float* b, float* y, float alpha, float beta, int64_t n, void* stream);      /* y = alpha*a + beta*b (b may be NULL) */
 int tdvc_fill(float* y, float value, int64_t n, void* stream);
 

@@ -21,14 +21,15 @@ class Xform(C.Structure):
 class ConvDesc(C.Structure):
     _fields_ = [('kind', C.c_int32), ('B', C.c_int32), ('Cin', C.c_int32), ('Cout', C.c_int32),
                 ('Tin', C.c_int32), ('Tout', C.c_int32), ('K', C.c_int32), ('stride', C.c_int32),
-                ('dilation', C.c_int32), ('pad', C.c_int32), ('groups', C.c_int32), ('reflect', C.c_int32)]
+                ('dilation', C.c_int32), ('pad', C.c_int32), ('groups', C.c_int32), ('reflect', C.c_int32),
+                ('w_cin', C.c_int32), ('w_cin_off', C.c_int32)]
 
 
 class ConvFwdArgs(C.Structure):
     _fields_ = [('x', C.c_void_p), ('x_bs', C.c_int64), ('x_xf', Xform), ('w', C.c_void_p), ('bias', C.c_void_p),
                 ('res', C.c_void_p), ('res_bs', C.c_int64), ('post_act', C.c_int32), ('post_slope', C.c_float),
                 ('out_scale', C.c_float), ('add', C.c_void_p), ('add_bs', C.c_int64), ('y', C.c_void_p),
-                ('y_bs', C.c_int64)]
+                ('y_bs', C.c_int64), ('bias3', C.c_void_p)]
 
 
 class ConvDgradArgs(C.Structure):
@@ -68,6 +69,7 @@ SIGNATURES = {
     'tdvc_gather_ch_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'tdvc_concat_cond': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'tdvc_concat_cond_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _i, _i, _vp]),
+    'tdvc_edge_sum3': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'tdvc_axpby': (_i, [_vp, _vp, _vp, _f, _f, _i64, _vp]),
     'tdvc_fill': (_i, [_vp, _f, _i64, _vp]),
     'tdvc_cin_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),

@@ -11,7 +11,7 @@ template <int MODE> hipError_t launch_conv_wgrad(WgradP, int, int, hipStream_t);
 template <int MODE> hipError_t launch_conv_wgrad_scalar(WgradP, int, long, float*, hipStream_t);
 int wgrad_geometry(WgradP& p, int B, int* bpb_out);
 bool wgrad_mfma_supported(int J);
-hipError_t launch_slab_reduce(const float*, int, long, long, float*, hipStream_t);
+hipError_t launch_slab_reduce(const float*, int, long, long, float*, int, long, hipStream_t);
 hipError_t launch_bias_grad(const Opnd&, int, int, int, float*, hipStream_t);
 }  // namespace tdvc
 
@@ -34,6 +34,11 @@ static int check_desc(const tdvc_conv_desc* d) {
   if (d->stride > 1 && d->dilation != 1) return tdvc_fail(TDVC_EUNSUPPORTED, "strided conv with dilation");
   if (d->reflect && (d->stride != 1 || d->kind != TDVC_CONV)) return tdvc_fail(TDVC_EUNSUPPORTED, "reflect padding needs stride 1 conv");
   if (d->reflect && d->pad >= d->Tin) return tdvc_fail(TDVC_EINVAL, "reflect padding must be smaller than the input length");
+  if (d->w_cin < 0 || d->w_cin_off < 0) return tdvc_fail(TDVC_EINVAL, "conv desc: negative weight channel window");
+  if (d->w_cin > 0) {
+    if (d->groups != 1 || d->kind != TDVC_CONV) return tdvc_fail(TDVC_EUNSUPPORTED, "weight channel window needs a plain conv with groups == 1");
+    if (d->w_cin_off + d->Cin > d->w_cin) return tdvc_fail(TDVC_EINVAL, "conv desc: weight channel window out of range");
+  }
   if (d->kind == TDVC_CONV) {
     long expect = ((long)d->Tin + 2L * d->pad - (long)d->dilation * (d->K - 1) - 1) / d->stride + 1;
     if (expect != d->Tout) return tdvc_fail(TDVC_EINVAL, "conv desc: Tout does not match conv arithmetic");
@@ -75,12 +80,13 @@ extern "C" int tdvc_conv_fwd(const tdvc_conv_desc* d, const tdvc_conv_fwd_args* 
   p.x.p = a->x; p.x.bs = a->x_bs; p.x.T = d->Tin; p.x.Cg = Cin_g; p.x.xf = to_xf(a->x_xf);
   p.w = a->w; p.K = d->K; p.s = d->stride; p.pad = d->pad; p.groups = d->groups;
   p.y = a->y; p.y_bs = a->y_bs; p.Ty = d->Tout; p.Cy_g = Cout_g;
-  p.epi = EPI_FWD; p.bias = a->bias; p.res = a->res; p.res_bs = a->res_bs;
+  p.epi = EPI_FWD; p.bias = a->bias; p.bias3 = a->bias3; p.res = a->res; p.res_bs = a->res_bs;
   p.post = a->post_act; p.post_slope = a->post_slope; p.out_scale = a->out_scale == 0.f ? 1.f : a->out_scale;
   p.add = a->add; p.add_bs = a->add_bs; p.add_scale = 1.f;
   p.w_sg = (long)Cout_g * Cin_g * d->K;
   if (d->kind == TDVC_CONV) {
     p.w_sm = (long)Cin_g * d->K; p.w_sc = d->K;
+    if (d->w_cin > 0) { p.w_sm = (long)d->w_cin * d->K; p.w += (long)d->w_cin_off * d->K; }
     p.R = Cout_g; p.N = d->Tout;
     if (d->stride == 1) { p.mode = MODE_DIRECT; p.Cred = Cin_g; p.J = d->K; p.d = d->dilation; p.reflect = d->reflect; }
     else { p.mode = MODE_DOWN; p.Cred = Cin_g * d->stride; p.J = ceil_div(d->K, d->stride); p.d = 1; }
@@ -115,6 +121,7 @@ extern "C" int tdvc_conv_dgrad(const tdvc_conv_desc* d, const tdvc_conv_dgrad_ar
   }
   if (d->kind == TDVC_CONV) {
     p.w_sm = d->K; p.w_sc = (long)Cin_g * d->K;      // rows = input channel, reduced channel = output channel
+    if (d->w_cin > 0) { p.w_sc = (long)d->w_cin * d->K; p.w += (long)d->w_cin_off * d->K; }
     if (d->stride == 1) {
       p.mode = MODE_DIRECT; p.R = Cin_g; p.Cred = Cout_g; p.J = d->K; p.d = d->dilation; p.tap_flip = 1;
       p.pad = (d->K - 1) * d->dilation - d->pad;
@@ -184,10 +191,16 @@ extern "C" int tdvc_conv_wgrad(const tdvc_conv_desc* d, const tdvc_conv_wgrad_ar
       if (!a->workspace || a->workspace_bytes < need) return tdvc_fail(TDVC_EWORKSPACE, "conv_wgrad: workspace too small");
       p.slab = (float*)a->workspace; p.slab_stride = wsize;
       e = p.mode == MODE_DIRECT ? launch_conv_wgrad<MODE_DIRECT>(p, d->B, bpb, st) : launch_conv_wgrad<MODE_DOWN>(p, d->B, bpb, st);
-      if (e == hipSuccess) e = launch_slab_reduce(p.slab, nslab, wsize, wsize, a->dw, st);
+      if (e == hipSuccess) {
+        const int rowlen = (int)p.w_sm;   // compact slab rows: [Cin_g*K]
+        if (d->w_cin > 0) e = launch_slab_reduce(p.slab, nslab, wsize, wsize, a->dw + (long)d->w_cin_off * d->K, rowlen, (long)d->w_cin * d->K, st);
+        else e = launch_slab_reduce(p.slab, nslab, wsize, wsize, a->dw, rowlen, rowlen, st);
+      }
     } else {
-      e = p.mode == MODE_DIRECT ? launch_conv_wgrad_scalar<MODE_DIRECT>(p, d->B, wsize, a->dw, st)
-                                : launch_conv_wgrad_scalar<MODE_DOWN>(p, d->B, wsize, a->dw, st);
+      float* dw_base = a->dw;
+      if (d->w_cin > 0) { p.w_sm = (long)d->w_cin * d->K; dw_base += (long)d->w_cin_off * d->K; }
+      e = p.mode == MODE_DIRECT ? launch_conv_wgrad_scalar<MODE_DIRECT>(p, d->B, wsize, dw_base, st)
+                                : launch_conv_wgrad_scalar<MODE_DOWN>(p, d->B, wsize, dw_base, st);
     }
     if (e != hipSuccess) return tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));
   }

@@ -39,6 +39,7 @@ struct GemmConvP {
   float* y; long y_bs; int Ty; int Cy_g;
   int epi;
   const float* bias;
+  const float* bias3;           // [B][Ctot][3] edge/interior/edge bias
   const float* res; long res_bs;
   int post; float post_slope; float out_scale;
   const float* add; long add_bs; float add_scale;
@@ -54,7 +55,6 @@ struct WgradP {
   int ntiles;                   // time chunks per sample
   float* slab; long slab_stride; // slab[(b*ntiles+tile)][groups*R*Cx_g*K (+ bias rows)]
   long w_sg, w_sm, w_sc;        // slab element index = g*w_sg + m*w_sm + c*w_sc + k
-  int with_bias; long bias_off; // bias partial sums at slab[.. + bias_off + g*R + m]
 };
 
 __device__ __forceinline__ float lrelu_f(float v, float s) { return v > 0.f ? v : v * s; }

@@ -15,6 +15,7 @@ __device__ __forceinline__ void conv_epilogue(const GemmConvP& p, float acc, int
   float v = acc;
   if (p.epi == EPI_FWD) {
     if (p.bias) v += p.bias[ch];
+    if (p.bias3) v += p.bias3[((long)b * Ctot + ch) * 3 + (u == 0 ? 0 : (u == p.Ty - 1 ? 2 : 1))];
     if (p.res) v += p.res[(long)b * p.res_bs + oi];
     if (p.post == POST_LRELU) v = lrelu_f(v, p.post_slope);
     else if (p.post == POST_TANH) v = tanhf(v);
@@ -382,12 +383,17 @@ __global__ __launch_bounds__(256) void conv_bias_grad_kernel(const Opnd a, int N
   if (threadIdx.x == 0) atomicAdd(&dbias[ch], sh[0] + sh[1] + sh[2] + sh[3]);
 }
 
-// dw[i] += sum_s slab[s][i]
-__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, int nslab, long stride, long n, float* dw) {
+// dw[map(i)] += sum_s slab[s][i]; grid.y splits the slabs so small weights still fill the chip.
+// map: compact row-major [rows][rowlen] -> dst row stride (channel-window weights), identity otherwise.
+__global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, int nslab, long stride, long n, float* dw,
+                                                          int rowlen, long dst_row_stride, int per_y) {
+  const int s0 = blockIdx.y * per_y, s1 = min(nslab, s0 + per_y);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     float s = 0.f;
-    for (int k = 0; k < nslab; ++k) s += slab[(long)k * stride + i];
-    dw[i] += s;
+    for (int k = s0; k < s1; ++k) s += slab[(long)k * stride + i];
+    long dst = i;
+    if (dst_row_stride != rowlen) { const long r = i / rowlen; dst = r * dst_row_stride + (i - r * rowlen); }
+    if (gridDim.y == 1) dw[dst] += s; else atomicAdd(&dw[dst], s);
   }
 }
 
@@ -557,9 +563,14 @@ hipError_t launch_conv_wgrad_scalar(WgradP p, int B, long nweights, float* dw, h
 template hipError_t launch_conv_wgrad_scalar<MODE_DIRECT>(WgradP, int, long, float*, hipStream_t);
 template hipError_t launch_conv_wgrad_scalar<MODE_DOWN>(WgradP, int, long, float*, hipStream_t);
 
-hipError_t launch_slab_reduce(const float* slab, int nslab, long stride, long n, float* dw, hipStream_t st) {
+hipError_t launch_slab_reduce(const float* slab, int nslab, long stride, long n, float* dw, int rowlen, long dst_row_stride,
+                              hipStream_t st) {
   int gx = (int)((n + 255) / 256); if (gx > 2048) gx = 2048; if (gx < 1) gx = 1;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(gx), dim3(256), 0, st, slab, nslab, stride, n, dw);
+  int gy = 1;
+  if (nslab > 8) { gy = 1024 / gx; if (gy > (nslab + 7) / 8) gy = (nslab + 7) / 8; if (gy < 1) gy = 1; }
+  const int per_y = (nslab + gy - 1) / gy;
+  gy = (nslab + per_y - 1) / per_y;
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(gx, gy), dim3(256), 0, st, slab, nslab, stride, n, dw, rowlen, dst_row_stride, per_y);
   return hipGetLastError();
 }
 

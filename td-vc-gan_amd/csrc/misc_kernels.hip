@@ -152,6 +152,17 @@ __global__ __launch_bounds__(256) void concat_cond_bwd_kernel(const float* dc, f
   }
 }
 
+// one block per (c, b) row: first element, interior sum, last element
+__global__ __launch_bounds__(256) void edge_sum3_kernel(const float* d, float* out, int C, int T) {
+  __shared__ float sh[4];
+  const int c = blockIdx.x, b = blockIdx.y;
+  const float* r = d + ((long)b * C + c) * T;
+  float s = 0.f;
+  for (int t = 1 + threadIdx.x; t < T - 1; t += 256) s += r[t];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) { float* o = out + ((long)b * C + c) * 3; o[0] = r[0]; o[1] = s; o[2] = r[T - 1]; }
+}
+
 __global__ __launch_bounds__(256) void axpby_kernel(const float* a, const float* b, float* y, float alpha, float beta, long n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256)
     y[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
@@ -437,6 +448,11 @@ extern "C" int tdvc_concat_cond(const float* emb, const float* exc, float* c, in
 }
 extern "C" int tdvc_concat_cond_bwd(const float* dc, float* demb, float* dexc, int B, int Ce, int Cx, int T, int accumulate_emb, void* stream) {
   hipLaunchKernelGGL(concat_cond_bwd_kernel, dim3(Ce + Cx, B), dim3(256), 0, (hipStream_t)stream, dc, demb, dexc, Ce, Cx, T, accumulate_emb);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+extern "C" int tdvc_edge_sum3(const float* d, float* out, int B, int C, int T, void* stream) {
+  if (T < 3) return tdvc_fail(TDVC_EINVAL, "edge_sum3: T must be >= 3");
+  hipLaunchKernelGGL(edge_sum3_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, d, out, C, T);
   TDVC_CHECK_LAUNCH(); return TDVC_OK;
 }
 extern "C" int tdvc_axpby(const float* a, const float* b, float* y, float alpha, float beta, int64_t n, void* stream) {

@@ -133,6 +133,9 @@ class ArenaModule(nn.Module):
                 if any((name + '.').startswith(d) for d in self.dead_prefixes):
                     continue
                 m.spec.slot = self._arena.slot(name, m.has_bias)
+        for m in self.modules():
+            if hasattr(m, 'on_slots_bound'):
+                m.on_slots_bound()
         self._arena.materialize()
         return self._arena
 
@@ -158,11 +161,30 @@ class FiLMResnetBlock(nn.Module):
         if self.has_cond:
             nc = n_cond_const + n_cond_var
             self.cond_var = nn.Sequential(ConvParams(nc, nc, 3, pad=1), nn.LeakyReLU(SLOPE), ConvParams(nc, n_channel * 2, 3, pad=1))
+            # exact split of cond_var.0 over its input channels (SURVEY §2.2 reduction 2): the n_cond_const
+            # speaker-embedding channels are constant in time, so their contribution is a per-(sample, channel)
+            # constant with a one-sample correction at each zero-padded edge == the same conv on a length-3 signal
+            self.n_const, self.n_var = n_cond_const, n_cond_var
+            self.spec_const = ConvSpec(n_cond_const, nc, 3, pad=1, w_cin=nc, w_cin_off=0)
+            self.spec_var = ConvSpec(n_cond_var, nc, 3, pad=1, w_cin=nc, w_cin_off=n_cond_const)
         self.shortcut = nn.Identity()
 
+    def on_slots_bound(self):
+        if self.has_cond and self.cond_var[0].spec.slot is not None:
+            s = self.cond_var[0].spec.slot
+            self.spec_const.slot = s                                             # carries the bias
+            self.spec_var.slot = ConvSlot(s.w, 0, s.dw, 0, s.trainable, s.arena)  # no bias on the time-varying part
+
     def forward(self, x, c=None, acc=None, scale=1.0):
+        """c: None (encoder), a dense [B,n_const+n_var,T] conditioning tensor (reference formulation), or a
+        (emb3 [B,n_const,3], exc [B,n_var,T]) pair for the split formulation."""
         gb = None
-        if c is not None:
+        if isinstance(c, tuple):
+            emb3, exc = c
+            k3 = ops.conv(emb3, self.spec_const)
+            cv = ops.conv(exc, self.spec_var, k3=k3)
+            gb = self.cond_var[2](cv, pre=PRE_LRELU)
+        elif c is not None:
             cv = self.cond_var[0](c)
             gb = self.cond_var[2](cv, pre=PRE_LRELU)
         return ops.film_block(x, gb, acc, self.conv[1].spec, self.posconv[1].spec, scale)
@@ -235,6 +257,7 @@ class Decoder(nn.Module):
     def __init__(self, ratios, channels, conditional_dim, embedding_dim):
         super().__init__()
         self.upsample_ratios = list(ratios)
+        self.split_cond = True      # False = the reference's dense 136-channel conditioning convs
         excite = [8] * (len(ratios) + 1)
         sub_out = [False, True, True, False]
         m = nn.ModuleList()
@@ -275,6 +298,8 @@ class Decoder(nn.Module):
             # the reference raises UnboundLocalError here (Q8); be explicit instead
             raise RuntimeError('Decoder.forward needs c_var (the F0 excitation): the reference has no path without it')
         pyr = self.get_scaled_conditioning(c_var.contiguous().float())
+        if self.split_cond:   # speaker embedding as a length-3 constant signal: [B,128] -> [B,128,3]
+            emb3 = ops.ConcatCondFn.apply(c, torch.empty((c.shape[0], 0, 3), dtype=torch.float32, device=c.device))
         subs = []
         scale = 0
         final_conv = len(self.decoder) - 2
@@ -283,7 +308,8 @@ class Decoder(nn.Module):
                 head = self.subsample_out_layers[scale]
                 if head is not None:
                     subs.append(head[1](x, pre=PRE_LRELU, post=L.POST_TANH))
-                cond = ops.ConcatCondFn.apply(c, pyr[len(pyr) - 1 - scale])
+                exc = pyr[len(pyr) - 1 - scale]
+                cond = (emb3, exc) if self.split_cond else ops.ConcatCondFn.apply(c, exc)
                 scale += 1
             if isinstance(mod, MRFBlock):
                 x = mod(x, cond)

@@ -23,9 +23,11 @@ def _stream(t):
 
 class ConvSpec:
     """Static description of one conv layer + where its tensors live (ConvSlot)."""
-    __slots__ = ('kind', 'cin', 'cout', 'k', 'stride', 'dil', 'pad', 'groups', 'reflect', 'slot', 'out_pad')
+    __slots__ = ('kind', 'cin', 'cout', 'k', 'stride', 'dil', 'pad', 'groups', 'reflect', 'slot', 'out_pad', 'w_cin', 'w_cin_off')
 
-    def __init__(self, cin, cout, k, stride=1, pad=0, dil=1, groups=1, reflect=False, transposed=False, out_pad=0):
+    def __init__(self, cin, cout, k, stride=1, pad=0, dil=1, groups=1, reflect=False, transposed=False, out_pad=0,
+                 w_cin=0, w_cin_off=0):
+        self.w_cin, self.w_cin_off = w_cin, w_cin_off
         self.kind = L.CONV_TRANSPOSE if transposed else L.CONV
         self.cin, self.cout, self.k, self.stride, self.dil, self.pad = cin, cout, k, stride, dil, pad
         self.groups, self.reflect, self.out_pad = groups, int(reflect), out_pad
@@ -41,7 +43,7 @@ class ConvSpec:
             raise RuntimeError(f'Padding size should be less than the corresponding input dimension, but got: '
                                f'padding ({self.pad}, {self.pad}) at dimension 2 of input length {tin}')
         return L.ConvDesc(self.kind, B, self.cin, self.cout, tin, self.tout(tin), self.k, self.stride, self.dil,
-                          self.pad, self.groups, self.reflect)
+                          self.pad, self.groups, self.reflect, self.w_cin, self.w_cin_off)
 
 
 # ------------------------------------------------------------------------------- workspace
@@ -74,7 +76,8 @@ def _check_layout(t):
         raise L.TdvcError('operand must be [B,C,T] with contiguous (C,T) planes')
 
 
-def conv_fwd_raw(spec: ConvSpec, x, x_xf, post=L.POST_NONE, res=None, add=None, out_scale=1.0, out=None, w_ptr=None, b_ptr=None):
+def conv_fwd_raw(spec: ConvSpec, x, x_xf, post=L.POST_NONE, res=None, add=None, out_scale=1.0, out=None, w_ptr=None, b_ptr=None,
+                 bias3=None):
     B, _, tin = x.shape
     d = spec.desc(B, tin)
     y = out if out is not None else torch.empty((B, spec.cout, d.Tout), dtype=torch.float32, device=x.device)
@@ -83,7 +86,8 @@ def conv_fwd_raw(spec: ConvSpec, x, x_xf, post=L.POST_NONE, res=None, add=None, 
                       (b_ptr if b_ptr is not None else spec.slot.b) or None,
                       res.data_ptr() if res is not None else None, _bs(res) if res is not None else 0,
                       post, SLOPE, out_scale, add.data_ptr() if add is not None else None,
-                      _bs(add) if add is not None else 0, y.data_ptr(), _bs(y))
+                      _bs(add) if add is not None else 0, y.data_ptr(), _bs(y),
+                      bias3.data_ptr() if bias3 is not None else None)
     L.check(L.lib().tdvc_conv_fwd(C.byref(d), C.byref(a), _stream(x)))
     return y
 
@@ -125,15 +129,21 @@ PRE_NONE, PRE_LRELU = 0, 1
 
 
 class ConvFn(Function):
-    """y = post(conv(pre(x)) + bias) [+ add].  pre in {none, LeakyReLU}; post in {none, LeakyReLU, tanh}."""
+    """y = post(conv(pre(x)) + bias [+ k3]) [+ add].  pre in {none, LeakyReLU}; post in {none, LeakyReLU, tanh};
+    k3 [B,Cout,3] is a per-sample bias for (t == 0, interior, t == T-1) — the time-constant part of FiLM's
+    conditioning conv evaluated on a length-3 signal."""
 
     @staticmethod
-    def forward(ctx, x, add, token, spec, pre, post):
+    def forward(ctx, x, add, token, spec, pre, post, k3=None):
         x = x.contiguous()
         xf = _xf(L.XF_LRELU if pre == PRE_LRELU else L.XF_NONE)
-        y = conv_fwd_raw(spec, x, xf, post=post, add=add)
+        if k3 is not None:
+            if post != L.POST_NONE:
+                raise L.TdvcError('k3 bias is only supported without a post-activation')
+            k3 = k3.contiguous()
+        y = conv_fwd_raw(spec, x, xf, post=post, add=add, bias3=k3)
         ctx.spec, ctx.pre, ctx.post, ctx.tin = spec, pre, post, x.shape[2]
-        ctx.has_add = add is not None
+        ctx.has_add, ctx.has_k3 = add is not None, k3 is not None
         ctx.save_for_backward(x, y if post != L.POST_NONE else None)
         return y
 
@@ -156,7 +166,12 @@ class ConvFn(Function):
                 dx = conv_dgrad_raw(spec, dy, dy_xf, ctx.tin, L.DG_MASK_LRELU, x_in=x)
             else:
                 dx = conv_dgrad_raw(spec, dy, dy_xf, ctx.tin, L.DG_PLAIN)
-        return dx, (dy if ctx.has_add else None), None, None, None, None
+        dk3 = None
+        if ctx.has_k3:
+            B, Cc, T = dy.shape
+            dk3 = torch.empty((B, Cc, 3), dtype=torch.float32, device=dy.device)
+            L.check(L.lib().tdvc_edge_sum3(dy.data_ptr(), dk3.data_ptr(), B, Cc, T, _stream(dy)))
+        return dx, (dy if ctx.has_add else None), None, None, None, None, dk3
 
 
 def _token(*specs):
@@ -171,8 +186,8 @@ def _token(*specs):
     return None
 
 
-def conv(x, spec, pre=PRE_NONE, post=L.POST_NONE, add=None):
-    return ConvFn.apply(x, add, _token(spec), spec, pre, post)
+def conv(x, spec, pre=PRE_NONE, post=L.POST_NONE, add=None, k3=None):
+    return ConvFn.apply(x, add, _token(spec), spec, pre, post, k3)
 
 
 class FilmBlockFn(Function):

@@ -145,3 +145,23 @@ def test_train_step_vs_golden(dev, cfg_name, T):
             if abs(got_a - a) > TOL * (abs(a) + 1e-12):
                 bad[k] = (got_a, a)
         assert not bad, (name, dict(list(bad.items())[:5]))
+
+
+def test_split_conditioning_equals_dense(models, dev):
+    """The exact algebraic split of cond_var.0 (time-constant speaker channels on a length-3 signal + 8-channel
+    excitation conv) against the reference's dense 136-channel formulation, forward and parameter gradients."""
+    G, _ = models
+    bt = to_dev(pkg().synth.make_batch(2, 8960, seed=21), dev)
+    res = {}
+    for split in (False, True):
+        G.decoder.split_cond = split
+        G.arena.zero_grad()
+        y, subs = G(bt['signal_real'], bt['c_tgt'], c_var=bt['c_f0_conv'], out_subsample=True)
+        (y.square().mean() + subs[0].mean() + subs[1].square().mean()).backward()
+        torch.cuda.synchronize()
+        res[split] = (y.detach().clone(), {k: p.grad.detach().clone() for k, p in G.named_parameters() if p.grad is not None})
+    G.decoder.split_cond = True
+    assert rel_l2(res[True][0], res[False][0]) < 1e-5
+    errs = {k: rel_l2(res[True][1][k], g) for k, g in res[False][1].items()}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    assert worst[0][1] < 2e-4, worst
