@@ -81,6 +81,8 @@ typedef struct {
   const float* dy; int64_t dy_bs;    /* upstream gradient w.r.t. y */
   tdvc_xform dy_xf;                  /* e.g. MASK_LRELU with aux = y for post-activated layers; scale = out_scale */
   const float* w;
+  const float* wt;                   /* optional: the same weight pre-transposed to [Cin(_w)][Cout][K] (stride-1, groups==1 convs);
+                                        lets the input-grad kernel stream contiguous weight rows (written by tdvc_weight_norm_fwd) */
   int32_t epilogue;                  /* tdvc_dgrad_epilogue */
   const float* x_in; int64_t x_in_bs; float slope; /* tensor the forward prologue read (mask / FiLM source) */
   const float* gb; int64_t gb_bs;    /* FiLM gamma/beta (TDVC_DG_FILM) */
@@ -111,6 +113,11 @@ void tdvc_set_force_generic(int on);
  * the element offsets of v / g in `params`, of w in `w`, and the row length. */
 int tdvc_weight_norm_fwd(const float* params, float* w, const int64_t* row_voff, const int64_t* row_goff,
                          const int64_t* row_woff, const int32_t* row_len, int nrows, void* stream);
+/* Same, additionally writing the [Cin][Cout][K] transposed copy of selected tensors into `wt`: per row, row_tbase =
+ * offset of element (ci=0, co=row, k=0) in wt, row_tstride = Cout*K, row_k = K (0 = tensor has no transposed copy). */
+int tdvc_weight_norm_fwd_t(const float* params, float* w, float* wt, const int64_t* row_voff, const int64_t* row_goff,
+                           const int64_t* row_woff, const int32_t* row_len, const int64_t* row_tbase,
+                           const int64_t* row_tstride, const int32_t* row_k, int nrows, void* stream);
 /* grads[v] (+)= g/||v|| * (dw - v <dw,v>/||v||^2), grads[g] (+)= <dw,v>/||v||; `grads` mirrors `params`. */
 int tdvc_weight_norm_bwd(const float* params, const float* dw, float* grads, const int64_t* row_voff,
                          const int64_t* row_goff, const int64_t* row_woff, const int32_t* row_len, int nrows,

@@ -143,7 +143,16 @@ def main():
                 worst = max(worst, rel(sg[k].grad, p.grad))
         pin[f'gen_grad_{tag}'] = worst
         norms, samples = grad_summary(ref_grads)
-        json.dump(dict(loss=float(loss), norms=norms, samples=samples), open(f'{OUT}/gen_grad_{tag}.json', 'w'))
+        # fp32 noise floor per tensor: the same oracle graph evaluated in float64. Gradients that are sums with
+        # heavy cancellation (bias / weight_g of late layers) are only defined to ~1e-3 in fp32 whatever the
+        # summation order, so the GPU parity test uses tol_k = max(1e-3, 5 * noise_k).
+        s64 = {k: v.double().clone().requires_grad_(True) for k, v in sd_g.items()}
+        y64, sub64, e64 = OM.generator(s64, bt['signal_real'].double(), bt['c_tgt'].double(), bt['c_f0_conv'].double())
+        sum((t * c.double()).mean() for t, c in zip((y64, sub64[0], sub64[1], e64), cot)).backward()
+        noise = {k: (rel(sg[k].grad, s64[k].grad) if s64[k].grad is not None and float(s64[k].grad.abs().max()) > 0 else 0.0)
+                 for k in sd_g}
+        pin[f'gen_grad_noise_{tag}'] = max(noise.values())
+        json.dump(dict(loss=float(loss), norms=norms, samples=samples, noise=noise), open(f'{OUT}/gen_grad_{tag}.json', 'w'))
 
         # discriminator on (real, fake)
         fake = y.detach()
@@ -164,11 +173,17 @@ def main():
             subs=max(rel(a, b) for a, b in zip(OM.disc_subsamples(bt['signal_real']), rsubs)),
             grads=max(rel(sdd[k].grad, p.grad) for k, p in D.named_parameters()), loss=abs(float(odl) - float(dloss)))
         norms, samples = grad_summary({k: p.grad for k, p in D.named_parameters()})
+        d64 = {k: v.double().clone().requires_grad_(True) for k, v in sd_d.items()}
+        xr64 = bt['signal_real'].double()
+        a_r, _ = OM.discriminator(d64, xr64, bt['label_src'], OM.disc_subsamples(xr64))
+        a_f, _ = OM.discriminator(d64, fake.double(), bt['label_tgt'], [s_.double() for s_ in fsubs])
+        (OL.lsgan_to_one(a_r) + OL.lsgan_to_zero(a_f)).backward()
+        dnoise = {k: rel(sdd[k].grad, d64[k].grad) for k in sd_d}
         arrs = {f'out_real_{i}': o.detach().numpy() for i, o in enumerate(o_r)}
         arrs.update({f'out_fake_{i}': o.detach().numpy() for i, o in enumerate(o_f)})
         arrs.update({f'sub_real_{i}': s.detach().numpy() for i, s in enumerate(rsubs)})
         np.savez_compressed(f'{OUT}/disc_{tag}.npz', **arrs)
-        json.dump(dict(loss=float(dloss), norms=norms, samples=samples,
+        json.dump(dict(loss=float(dloss), norms=norms, samples=samples, noise=dnoise,
                        feat_stats_real=[[feat_stats(f) for f in fl] for fl in f_r],
                        feat_stats_fake=[[feat_stats(f) for f in fl] for fl in f_f]),
                   open(f'{OUT}/disc_{tag}.json', 'w'))

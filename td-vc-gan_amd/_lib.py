@@ -33,7 +33,7 @@ class ConvFwdArgs(C.Structure):
 
 
 class ConvDgradArgs(C.Structure):
-    _fields_ = [('dy', C.c_void_p), ('dy_bs', C.c_int64), ('dy_xf', Xform), ('w', C.c_void_p),
+    _fields_ = [('dy', C.c_void_p), ('dy_bs', C.c_int64), ('dy_xf', Xform), ('w', C.c_void_p), ('wt', C.c_void_p),
                 ('epilogue', C.c_int32), ('x_in', C.c_void_p), ('x_in_bs', C.c_int64), ('slope', C.c_float),
                 ('gb', C.c_void_p), ('gb_bs', C.c_int64), ('dgb', C.c_void_p), ('dgb_bs', C.c_int64),
                 ('add', C.c_void_p), ('add_bs', C.c_int64), ('add_scale', C.c_float),
@@ -60,6 +60,7 @@ SIGNATURES = {
     'tdvc_conv_wgrad_workspace': (C.c_size_t, [C.POINTER(ConvDesc)]),
     'tdvc_set_force_generic': (None, [_i]),
     'tdvc_weight_norm_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
+    'tdvc_weight_norm_fwd_t': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'tdvc_weight_norm_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     'tdvc_adamw': (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp, _f, _vp]),
     'tdvc_inc_i32': (_i, [_vp, C.c_int32, _vp]),

@@ -17,14 +17,16 @@ from . import _lib as L
 
 class ConvSlot:
     """Raw device addresses of one conv layer's tensors inside the arenas."""
-    __slots__ = ('w', 'b', 'dw', 'db', 'trainable', 'arena')
+    __slots__ = ('w', 'b', 'dw', 'db', 'trainable', 'arena', 'wt')
 
-    def __init__(self, w=0, b=0, dw=0, db=0, trainable=True, arena=None):
-        self.w, self.b, self.dw, self.db, self.trainable, self.arena = w, b, dw, db, trainable, arena
+    def __init__(self, w=0, b=0, dw=0, db=0, trainable=True, arena=None, wt=0):
+        self.w, self.b, self.dw, self.db, self.trainable, self.arena, self.wt = w, b, dw, db, trainable, arena, wt
 
 
 class ParamArena:
-    def __init__(self, module: torch.nn.Module, device, dead_prefixes=()):
+    def __init__(self, module: torch.nn.Module, device, dead_prefixes=(), transposable=()):
+        """transposable: prefixes of weight-normed stride-1, groups==1 convs whose effective weight is also kept
+        pre-transposed as [Cin][Cout][K] (arena WT) for the input-gradient kernel."""
         named = list(module.named_parameters())
         live = [(k, p) for k, p in named if not any(k.startswith(d) for d in dead_prefixes)]
         dead = [(k, p) for k, p in named if any(k.startswith(d) for d in dead_prefixes)]
@@ -60,16 +62,22 @@ class ParamArena:
                 woff += (p.numel() + 3) // 4 * 4
         self.n_w = max(woff, 4)
         self.W = torch.zeros(self.n_w, dtype=torch.float32, device=self.device)
+        self.WT = torch.zeros(self.n_w, dtype=torch.float32, device=self.device)
         self.dW = torch.zeros(self.n_w, dtype=torch.float32, device=self.device)
+        self.transposed = set(t for t in transposable)
         self.w_offsets = {pre: wo for pre, _, _, wo, _, _ in self.wn}
         if self.wn:
-            rv, rg, rw, rl = [], [], [], []
-            for _, vo, go, wo, rows, cols in self.wn:
+            rv, rg, rw, rl, tb, ts, tk = [], [], [], [], [], [], []
+            for pre, vo, go, wo, rows, cols in self.wn:
+                K = self.params[pre + '.weight_v'].shape[2]
+                tr = pre in self.transposed
                 for r in range(rows):
                     rv.append(vo + r * cols); rg.append(go + r); rw.append(wo + r * cols); rl.append(cols)
+                    tb.append(wo + r * K); ts.append(rows * K); tk.append(K if tr else 0)
             t = lambda a, dt: torch.tensor(a, dtype=dt, device=self.device)
             self.row_voff, self.row_goff, self.row_woff = t(rv, torch.int64), t(rg, torch.int64), t(rw, torch.int64)
             self.row_len = t(rl, torch.int32)
+            self.row_tbase, self.row_tstride, self.row_k = t(tb, torch.int64), t(ts, torch.int64), t(tk, torch.int32)
             self.nrows = len(rl)
         else:
             self.nrows = 0
@@ -92,7 +100,8 @@ class ParamArena:
         if has_bias:
             o = self.offsets[prefix + '.bias']
             b, db = pb + 4 * o, gb + 4 * o
-        return ConvSlot(w, b, dw, db, True, self)
+        wt = self.WT.data_ptr() + 4 * self.w_offsets[prefix] if prefix in self.transposed else 0
+        return ConvSlot(w, b, dw, db, True, self, wt)
 
     def owns(self, p: torch.Tensor) -> bool:
         a = p.data_ptr()
@@ -103,9 +112,11 @@ class ParamArena:
         """w = g * v / ||v|| for every weight-normed tensor: one launch."""
         if self.nrows:
             st = torch.cuda.current_stream(self.device).cuda_stream
-            L.check(L.lib().tdvc_weight_norm_fwd(self.P.data_ptr(), self.W.data_ptr(), self.row_voff.data_ptr(),
-                                                 self.row_goff.data_ptr(), self.row_woff.data_ptr(),
-                                                 self.row_len.data_ptr(), self.nrows, st))
+            L.check(L.lib().tdvc_weight_norm_fwd_t(self.P.data_ptr(), self.W.data_ptr(), self.WT.data_ptr(),
+                                                   self.row_voff.data_ptr(), self.row_goff.data_ptr(),
+                                                   self.row_woff.data_ptr(), self.row_len.data_ptr(),
+                                                   self.row_tbase.data_ptr(), self.row_tstride.data_ptr(),
+                                                   self.row_k.data_ptr(), self.nrows, st))
 
     def zero_grad(self):
         self.G.zero_()

@@ -15,7 +15,43 @@ hipError_t launch_slab_reduce(const float*, int, long, long, float*, int, long, 
 hipError_t launch_bias_grad(const Opnd&, int, int, int, float*, hipStream_t);
 }  // namespace tdvc
 
+namespace tdvc {
+enum { LXF_ACT = 0, LXF_FILM = 1, LXF_MASK_LRELU = 2, LXF_MASK_TANH = 3 };
+struct LeanP {
+  const float* x; const float* w; float* y;
+  const float* bias; const float* bias3; const float* res; const float* add;
+  const float* aux;
+  const float* mx; const float* gb; float* dgb;
+  int x_bs, y_bs, res_bs, add_bs, aux_bs, mx_bs, gb_bs, dgb_bs;
+  int T, Cin, Cout, Cw, K, d, pad, flip, reflect, mirror;
+  int Cc, span, lo, i0, XS, WS;
+  int post;
+  float slope, in_scale, out_scale, add_scale, m_slope;
+};
+hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st);
+}  // namespace tdvc
+
 using namespace tdvc;
+
+static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
+static inline bool ok_bs(const void* p, long bs) { return !p || (al16(p) && (bs & 3) == 0 && bs < (1L << 31)); }
+
+// Prologue kind of the lean kernel for an operand transform; -1 = not supported there.
+static int lean_xfk(const tdvc_xform& x, float* slope, float* scale, const float** aux, long* aux_bs) {
+  *scale = x.scale == 0.f ? 1.f : x.scale; *aux = x.aux; *aux_bs = x.aux_bs; *slope = x.slope;
+  switch (x.kind) {
+    case TDVC_XF_NONE: *slope = 1.f; *aux = nullptr; return LXF_ACT;
+    case TDVC_XF_LRELU: *aux = nullptr; return (x.slope >= 0.f && x.slope <= 1.f) ? LXF_ACT : -1;
+    case TDVC_XF_FILM_LRELU: return (x.slope >= 0.f && x.slope <= 1.f) ? LXF_FILM : -1;
+    case TDVC_XF_MASK_LRELU: return LXF_MASK_LRELU;
+    case TDVC_XF_MASK_TANH: return LXF_MASK_TANH;
+    default: return -1;
+  }
+}
+
+static bool lean_shape_ok(const tdvc_conv_desc* d) {
+  return d->kind == TDVC_CONV && d->stride == 1 && d->groups == 1 && d->Tin == d->Tout && (d->Tin & 3) == 0;
+}
 
 static int g_force_generic = 0;
 extern "C" void tdvc_set_force_generic(int on) { g_force_generic = on; }
@@ -76,6 +112,24 @@ extern "C" int tdvc_conv_fwd(const tdvc_conv_desc* d, const tdvc_conv_fwd_args* 
   if (int rc = check_desc(d)) return rc;
   if (!a || !a->x || !a->w || !a->y) return tdvc_fail(TDVC_EINVAL, "conv_fwd: null pointer");
   const int Cin_g = d->Cin / d->groups, Cout_g = d->Cout / d->groups;
+  if (!g_force_generic && lean_shape_ok(d) && (d->Cin & 3) == 0) {
+    LeanP q = {};
+    float slope, scale; const float* aux; long aux_bs;
+    const int xfk = lean_xfk(a->x_xf, &slope, &scale, &aux, &aux_bs);
+    const int cw = (d->w_cin > 0 ? d->w_cin : d->Cin) * d->K;
+    const float* w = a->w + (long)d->w_cin_off * d->K;
+    if (xfk >= 0 && (cw & 3) == 0 && al16(w) && ok_bs(a->x, a->x_bs) && ok_bs(a->y, a->y_bs) && ok_bs(a->res, a->res_bs) &&
+        ok_bs(a->add, a->add_bs) && ok_bs(aux, aux_bs)) {
+      q.x = a->x; q.w = w; q.y = a->y; q.bias = a->bias; q.bias3 = a->bias3; q.res = a->res; q.add = a->add; q.aux = aux;
+      q.x_bs = (int)a->x_bs; q.y_bs = (int)a->y_bs; q.res_bs = (int)a->res_bs; q.add_bs = (int)a->add_bs; q.aux_bs = (int)aux_bs;
+      q.T = d->Tin; q.Cin = d->Cin; q.Cout = d->Cout; q.Cw = cw; q.K = d->K; q.d = d->dilation; q.pad = d->pad; q.reflect = d->reflect;
+      q.post = a->post_act; q.slope = slope; q.in_scale = scale; q.out_scale = a->out_scale == 0.f ? 1.f : a->out_scale;
+      q.add_scale = 1.f; q.m_slope = a->post_slope;
+      hipError_t e = launch_conv_lean(q, d->B, xfk, EPI_FWD, (hipStream_t)stream);
+      if (e == hipSuccess) return TDVC_OK;
+      if (e != hipErrorNotSupported) return tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));
+    }
+  }
   GemmConvP p = {};
   p.x.p = a->x; p.x.bs = a->x_bs; p.x.T = d->Tin; p.x.Cg = Cin_g; p.x.xf = to_xf(a->x_xf);
   p.w = a->w; p.K = d->K; p.s = d->stride; p.pad = d->pad; p.groups = d->groups;
@@ -102,6 +156,27 @@ extern "C" int tdvc_conv_dgrad(const tdvc_conv_desc* d, const tdvc_conv_dgrad_ar
   if (int rc = check_desc(d)) return rc;
   if (!a || !a->dy || !a->w || !a->dx) return tdvc_fail(TDVC_EINVAL, "conv_dgrad: null pointer");
   const int Cin_g = d->Cin / d->groups, Cout_g = d->Cout / d->groups;
+  if (!g_force_generic && a->wt && lean_shape_ok(d) && (d->Cout & 3) == 0 && (d->K - 1) * d->dilation - d->pad >= 0) {
+    LeanP q = {};
+    float slope, scale; const float* aux; long aux_bs;
+    const int xfk = lean_xfk(a->dy_xf, &slope, &scale, &aux, &aux_bs);
+    const int cw = d->Cout * d->K;                                  // wt rows: [ci] -> (co, k) contiguous
+    const float* w = a->wt + (long)d->w_cin_off * cw;
+    const int epi = a->epilogue == TDVC_DG_PLAIN ? EPI_PLAIN : (a->epilogue == TDVC_DG_MASK_LRELU ? EPI_MASK : EPI_FILM);
+    if (xfk >= 0 && (cw & 3) == 0 && al16(w) && ok_bs(a->dy, a->dy_bs) && ok_bs(a->dx, a->dx_bs) && ok_bs(a->add, a->add_bs) &&
+        ok_bs(aux, aux_bs) && ok_bs(a->x_in, a->x_in_bs) && ok_bs(a->gb, a->gb_bs) && ok_bs(a->dgb, a->dgb_bs) &&
+        (epi == EPI_PLAIN || a->x_in) && (epi != EPI_FILM || (a->gb && a->dgb))) {
+      q.x = a->dy; q.w = w; q.y = a->dx; q.add = a->add; q.aux = aux; q.mx = a->x_in; q.gb = a->gb; q.dgb = a->dgb;
+      q.x_bs = (int)a->dy_bs; q.y_bs = (int)a->dx_bs; q.add_bs = (int)a->add_bs; q.aux_bs = (int)aux_bs; q.mx_bs = (int)a->x_in_bs;
+      q.gb_bs = (int)a->gb_bs; q.dgb_bs = (int)a->dgb_bs;
+      q.T = d->Tin; q.Cin = d->Cout; q.Cout = d->Cin; q.Cw = cw; q.K = d->K; q.d = d->dilation;
+      q.pad = (d->K - 1) * d->dilation - d->pad; q.flip = 1; q.mirror = d->reflect ? d->pad : 0;
+      q.slope = slope; q.in_scale = scale; q.out_scale = 1.f; q.add_scale = a->add_scale; q.m_slope = a->slope;
+      hipError_t e = launch_conv_lean(q, d->B, xfk, epi, (hipStream_t)stream);
+      if (e == hipSuccess) return TDVC_OK;
+      if (e != hipErrorNotSupported) return tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));
+    }
+  }
   GemmConvP p = {};
   p.x.p = a->dy; p.x.bs = a->dy_bs; p.x.T = d->Tout; p.x.Cg = Cout_g; p.x.xf = to_xf(a->dy_xf);
   p.w = a->w; p.K = d->K; p.s = d->stride; p.groups = d->groups;

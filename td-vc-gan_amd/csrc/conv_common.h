@@ -34,8 +34,10 @@ struct GemmConvP {
   const float* w; long w_sg, w_sm, w_sc; int K; int tap_flip;   // A[r][c][k] = w[g*w_sg + m*w_sm + c*w_sc + k]
   int mode, s, d, pad, reflect, J;
   int R, Cred, Cc, N, groups, lo, span, XS, WS;
+  int i0;                       // staged index read by column n0, tap 0 (= first tap position - lo)
   int mirror_pad;               // > 0: fold reflect-pad halo (dgrad of a reflect conv)
   int stage_rows;               // DOWN with a large stride: stage with lanes along the reduced rows
+  int w_nat;                    // weight rows are contiguous over (c,k) and float4-alignable (host-checked)
   float* y; long y_bs; int Ty; int Cy_g;
   int epi;
   const float* bias;
@@ -52,6 +54,7 @@ struct WgradP {
   Opnd x;                       // column operand (x-like)
   int mode, s, d, pad, reflect, J, K;
   int R, Cred, N, groups, lo, span, NTc, XS, AS;
+  int i0;
   int ntiles;                   // time chunks per sample
   float* slab; long slab_stride; // slab[(b*ntiles+tile)][groups*R*Cx_g*K (+ bias rows)]
   long w_sg, w_sm, w_sc;        // slab element index = g*w_sg + m*w_sm + c*w_sc + k
@@ -89,6 +92,95 @@ __device__ __forceinline__ float fetch_opnd(const Opnd& o, int b, int ch, int q,
   if (q < 0 || q >= o.T) return 0.f;
   float v = o.p[(long)b * o.bs + (long)ch * o.T + q];
   return apply_xf(o.xf, v, b, ch, q, o.T, Ctot);
+}
+
+
+typedef float f32x4_t __attribute__((ext_vector_type(4)));
+
+// True when rows [q0, q0+span) of operand `o` can be staged with aligned 16-byte loads and no padding logic.
+__device__ __forceinline__ bool rows_fast_ok(const Opnd& o, int q0, int span) {
+  return q0 >= 0 && q0 + span <= o.T && (o.T & 3) == 0 && (o.bs & 3) == 0 && ((q0 | span) & 3) == 0 &&
+         (((uintptr_t)o.p) & 15) == 0 &&
+         (o.xf.kind == XF_NONE || o.xf.kind == XF_LRELU || ((((uintptr_t)o.xf.aux) & 15) == 0 && (o.xf.aux_bs & 3) == 0));
+}
+
+// Register-staged row tiles, split into ISSUE (all global loads of a batch in flight at once) and COMMIT
+// (prologue transform + LDS write), so that HBM latency overlaps whatever runs in between (the MFMA loop
+// on the previous channel chunk) — cdna_hip_programming.md T14. Tile = nrows x span floats; element
+// e = ebase + tid + i*256 -> (row r, float4 v). Rows >= nvalid are zero-filled.
+template <int NV>
+struct RegTile { f32x4_t v[NV]; };
+
+template <int NV>
+__device__ __forceinline__ void tile_issue(RegTile<NV>& t, const float* base, int rowstride, int nvalid, int nrows, int span,
+                                           int cvalid /* valid floats per row, multiple of 4 */, int ebase, int tid) {
+  const int nvec = span >> 2, total = nrows * nvec;
+  const float inv = 1.0f / (float)nvec;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int e = ebase + tid + i * 256;
+    const int r = (int)(((float)e + 0.5f) * inv);
+    const int vv = e - r * nvec;
+    t.v[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
+    if (e < total && r < nvalid && 4 * vv < cvalid) t.v[i] = *reinterpret_cast<const f32x4_t*>(base + (long)r * rowstride + 4 * vv);
+  }
+}
+
+// kind NONE / LRELU use only `t`; MASK_* use `a` (activation output); FILM uses a = gamma, c = beta.
+template <int NV>
+__device__ __forceinline__ void tile_commit(const RegTile<NV>& t, const RegTile<NV>* a, const RegTile<NV>* c, const Xf& xf,
+                                            float* dst, int XS, int nvalid, int nrows, int span, int ebase, int tid) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  const int nvec = span >> 2, total = nrows * nvec;
+  const float inv = 1.0f / (float)nvec;
+  const int kind = xf.kind;
+  const float sl = xf.slope, sc = xf.scale;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int e = ebase + tid + i * 256;
+    if (e >= total) continue;
+    const int r = (int)(((float)e + 0.5f) * inv);
+    const int vv = e - r * nvec;
+    f32x4_t val = t.v[i];
+    if (r < nvalid) {
+      if (kind == XF_LRELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) val[q] = fmaxf(val[q], val[q] * sl);
+      } else if (kind == XF_FILM_LRELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) { const float h = val[q] * (1.f + a->v[i][q]) + c->v[i][q]; val[q] = fmaxf(h, h * sl); }
+      } else if (kind == XF_MASK_LRELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) val[q] = a->v[i][q] > 0.f ? val[q] : val[q] * sl;
+      } else if (kind == XF_MASK_TANH) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) val[q] = val[q] * (1.f - a->v[i][q] * a->v[i][q]);
+      }
+      if (sc != 1.f) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) val[q] *= sc;
+      }
+    }
+    f32x2_t* d2 = reinterpret_cast<f32x2_t*>(dst + r * XS + 4 * vv);   // rows are 8-byte aligned in every layout
+    d2[0] = (f32x2_t){val[0], val[1]};
+    d2[1] = (f32x2_t){val[2], val[3]};
+  }
+}
+
+// Whole tile, not pipelined: batches of NV float4 per thread (x up to 3 source tensors) in flight at a time.
+template <int NV>
+__device__ __forceinline__ void stage_rows_batched(const Opnd& o, float* dst, int XS, int b, int ch0, int nvalid, int nrows,
+                                                   int q0, int span, int Ctot, int tid) {
+  const int total = nrows * (span >> 2);
+  const float* base = o.p + (long)b * o.bs + (long)ch0 * o.T + q0;
+  const float* abase = o.xf.aux ? o.xf.aux + (long)b * o.xf.aux_bs + (long)ch0 * o.T + q0 : nullptr;
+  for (int eb = 0; eb < total; eb += NV * 256) {
+    RegTile<NV> t, a, c;
+    tile_issue<NV>(t, base, o.T, nvalid, nrows, span, span, eb, tid);
+    if (o.xf.kind >= XF_FILM_LRELU) tile_issue<NV>(a, abase, o.T, nvalid, nrows, span, span, eb, tid);
+    if (o.xf.kind == XF_FILM_LRELU) tile_issue<NV>(c, abase + (long)Ctot * o.T, o.T, nvalid, nrows, span, span, eb, tid);
+    tile_commit<NV>(t, &a, &c, o.xf, dst, XS, nvalid, nrows, span, eb, tid);
+  }
 }
 
 }  // namespace tdvc

@@ -1,0 +1,329 @@
+// Lean MFMA kernel for the hot stride-1 convolutions (dilated trunk convs, 1x1 posconvs, FiLM conditioning
+// convs, D layer 5) and their input-gradients: groups == 1, Tout == Tin, T % 4 == 0, Cin % 4 == 0, weights
+// with contiguous (c,k) rows (module layout for forward, the pre-transposed copy for input-grad).
+//
+// Differences from the generic kernel in conv_mfma.hip (which stays the fallback for strided / transposed /
+// grouped / odd shapes and for edge cases):
+//   * prologue kind and epilogue kind are template parameters -> no per-element switches, ~5x fewer VALU ops;
+//   * MFMA operand roles are swapped (A = input tile, B = weights) so that each lane owns 4 CONSECUTIVE time
+//     steps of one output channel: the epilogue reads/writes float4 (dwordx4) instead of scalars;
+//   * a compact parameter block (fits in SGPRs without spilling);
+//   * interior tiles stage through registers one channel chunk ahead of the MFMA loop (T14 split).
+#include "conv_common.h"
+
+namespace tdvc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+enum { LXF_ACT = 0, LXF_FILM = 1, LXF_MASK_LRELU = 2, LXF_MASK_TANH = 3 };   // prologue kinds (ACT: none or LeakyReLU by slope)
+
+struct LeanP {
+  const float* x; const float* w; float* y;
+  const float* bias; const float* bias3; const float* res; const float* add;
+  const float* aux;                    // prologue second tensor: FiLM gamma/beta or activation output
+  const float* mx; const float* gb; float* dgb;
+  int x_bs, y_bs, res_bs, add_bs, aux_bs, mx_bs, gb_bs, dgb_bs;
+  int T, Cin, Cout, Cw, K, d, pad, flip, reflect, mirror;
+  int Cc, span, lo, i0, XS, WS;
+  int post;
+  float slope, in_scale, out_scale, add_scale, m_slope;
+};
+
+template <int XFK>
+__device__ __forceinline__ float lean_xform(const LeanP& p, float v, int b, int c, int q) {
+  if (XFK == LXF_ACT) { v = fmaxf(v, v * p.slope); }
+  else {
+    const float* a = p.aux + (long)b * p.aux_bs + (long)c * p.T + q;
+    if (XFK == LXF_FILM) { const float h = v * (1.f + a[0]) + a[(long)p.Cin * p.T]; v = fmaxf(h, h * p.slope); }
+    else if (XFK == LXF_MASK_LRELU) { v = a[0] > 0.f ? v : v * p.slope; }
+    else { v = v * (1.f - a[0] * a[0]); }
+  }
+  return v * p.in_scale;
+}
+
+template <int XFK>
+__device__ __forceinline__ float lean_fetch(const LeanP& p, int b, int c, int q) {
+  if (p.reflect) { if (q < 0) q = -q; else if (q >= p.T) q = 2 * (p.T - 1) - q; }
+  if (q < 0 || q >= p.T) return 0.f;
+  return lean_xform<XFK>(p, p.x[(long)b * p.x_bs + (long)c * p.T + q], b, c, q);
+}
+
+template <int M_REP, int N_REP, int WM, int WN, int XFK, int EPI>
+__global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 2 : (M_REP * N_REP >= 8 ? 3 : 4))) void conv_lean_kernel(const LeanP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int MT = 16 * M_REP * WM, NT = 16 * N_REP * WN;
+  constexpr int XV = (XFK == LXF_ACT) ? (MT >= 64 ? 8 : 6) : 4;      // float4 per thread per staged tensor
+  constexpr int WVV = MT >= 64 ? 10 : (MT >= 32 ? 6 : 3);
+  float* xs = smem;
+  float* ws = smem + p.Cc * p.XS;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  const int ln = lane & 15, kq = lane >> 4;
+  const int n0 = blockIdx.x * NT, r0 = blockIdx.y * MT, b = blockIdx.z;
+  const int wcol0 = wn * 16 * N_REP, wrow0 = wm * 16 * M_REP;
+
+  f32x4 acc[M_REP][N_REP];
+#pragma unroll
+  for (int m = 0; m < M_REP; ++m)
+#pragma unroll
+    for (int n = 0; n < N_REP; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int q0 = n0 + p.lo;
+  const bool interior = q0 >= 0 && q0 + p.span <= p.T;
+  const int jc = p.K * p.Cc;
+  const float* xrow0 = p.x + (long)b * p.x_bs + q0;
+  const float* arow0 = (XFK != LXF_ACT) ? p.aux + (long)b * p.aux_bs + q0 : nullptr;
+  const float* wgrow = p.w + (long)r0 * p.Cw;
+  const int mvalid = min(MT, p.Cout - r0);
+  Xf xf; xf.kind = (XFK == LXF_ACT) ? XF_LRELU : (XFK == LXF_FILM ? XF_FILM_LRELU : (XFK == LXF_MASK_LRELU ? XF_MASK_LRELU : XF_MASK_TANH));
+  xf.slope = p.slope; xf.scale = p.in_scale; xf.aux = nullptr; xf.aux_bs = 0;
+  const Xf wxf = {XF_NONE, 0.f, 1.f, nullptr, 0};
+
+  RegTile<XV> xr;
+  RegTile<WVV> wr;
+  const bool xpipe = (XFK == LXF_ACT) && interior;
+  auto x_issue = [&](int c0) { tile_issue<XV>(xr, xrow0 + (long)c0 * p.T, p.T, min(p.Cc, p.Cin - c0), p.Cc, p.span, p.span, 0, tid); };
+  auto w_issue = [&](int c0) { tile_issue<WVV>(wr, wgrow + (long)c0 * p.K, p.Cw, mvalid, MT, jc, min(p.Cc, p.Cin - c0) * p.K, 0, tid); };
+  if (xpipe) x_issue(0);
+  w_issue(0);
+
+  bool needL = false, needR = false;
+  if (p.mirror > 0) {
+    const int c_lo = n0 + wcol0, c_hi = c_lo + 16 * N_REP - 1;
+    needL = (c_lo <= p.mirror) && (c_hi >= 1);
+    needR = (c_lo <= p.T - 2) && (c_hi >= p.T - 1 - p.mirror);
+  }
+
+  for (int c0 = 0; c0 < p.Cin; c0 += p.Cc) {
+    const int cvalid = min(p.Cc, p.Cin - c0);
+    __syncthreads();
+    if (xpipe) {
+      tile_commit<XV>(xr, nullptr, nullptr, xf, xs, p.XS, cvalid, p.Cc, p.span, 0, tid);
+    } else if (interior) {
+      const int total = p.Cc * (p.span >> 2);
+      for (int eb = 0; eb < total; eb += XV * 256) {
+        RegTile<XV> t, a, c;
+        tile_issue<XV>(t, xrow0 + (long)c0 * p.T, p.T, cvalid, p.Cc, p.span, p.span, eb, tid);
+        if (XFK != LXF_ACT) tile_issue<XV>(a, arow0 + (long)c0 * p.T, p.T, cvalid, p.Cc, p.span, p.span, eb, tid);
+        if (XFK == LXF_FILM) tile_issue<XV>(c, arow0 + (long)(p.Cin + c0) * p.T, p.T, cvalid, p.Cc, p.span, p.span, eb, tid);
+        tile_commit<XV>(t, &a, &c, xf, xs, p.XS, cvalid, p.Cc, p.span, eb, tid);
+      }
+    } else {   // edge tile: per-element padding logic
+      for (int r = wave; r < p.Cc; r += 4) {
+        float* row = xs + r * p.XS;
+        const bool rv = r < cvalid;
+        for (int i = lane; i < p.span; i += 64) row[i] = rv ? lean_fetch<XFK>(p, b, c0 + r, q0 + i) : 0.f;
+      }
+    }
+    tile_commit<WVV>(wr, nullptr, nullptr, wxf, ws, p.WS, mvalid, MT, jc, 0, tid);
+    __syncthreads();
+    if (c0 + p.Cc < p.Cin) {
+      if (xpipe) x_issue(c0 + p.Cc);
+      w_issue(c0 + p.Cc);
+    }
+
+    // MFMA: D[t][co] += X'[t][k] * W[k][co]; one step = 4 channels of one tap. Fragments of step s+1 are
+    // read from LDS into the other register set before the MFMAs of step s issue (software pipelining);
+    // the (tap, channel-group) walk is kept in scalar registers so a step costs 1 + M_REP vector adds.
+    const int csteps = p.Cc >> 2;
+    const int nsteps = p.K * csteps;
+    const float* w_lane = ws + (wrow0 + ln) * p.WS + kq * p.K;
+    const float* x_lane = xs + kq * p.XS + wcol0 + ln + p.i0;
+    const int wrep = 16 * p.WS;
+    int sj = 0, scs = 0;                                   // scalar walk state
+    int woff = p.flip ? p.K - 1 : 0, xoff = 0;
+    auto advance = [&]() {
+      if (++scs == csteps) { scs = 0; ++sj; woff = p.flip ? p.K - 1 - sj : sj; xoff = sj * p.d; }
+      else { woff += 4 * p.K; xoff += 4 * p.XS; }
+    };
+    float wv[2][M_REP], xv[2][N_REP];
+    auto load_frag = [&](int buf) {
+      const float* wp = w_lane + woff;
+      const float* xp = x_lane + xoff;
+#pragma unroll
+      for (int m = 0; m < M_REP; ++m) wv[buf][m] = wp[m * wrep];
+#pragma unroll
+      for (int n = 0; n < N_REP; ++n) xv[buf][n] = xp[n * 16];
+    };
+    auto mma = [&](int buf) {
+#pragma unroll
+      for (int m = 0; m < M_REP; ++m)
+#pragma unroll
+        for (int n = 0; n < N_REP; ++n)
+          acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[buf][n], wv[buf][m], acc[m][n], 0, 0, 0);
+    };
+    load_frag(0);
+    int s = 0;
+    for (; s + 2 <= nsteps; s += 2) {
+      advance(); load_frag(1);
+      mma(0);
+      if (s + 2 < nsteps) { advance(); load_frag(0); }
+      mma(1);
+    }
+    if (s < nsteps) mma(0);
+
+    if (needL || needR) {   // reflect-pad fold (input-grad of a reflect conv): edge waves only
+      for (int side = 0; side < 2; ++side) {
+        if (side == 0 ? !needL : !needR) continue;
+        int mb[N_REP]; bool mv[N_REP];
+#pragma unroll
+        for (int n = 0; n < N_REP; ++n) {
+          const int u = n0 + wcol0 + n * 16 + ln;
+          if (side == 0) { mv[n] = (u >= 1 && u <= p.mirror && u < p.T); mb[n] = -u - n0 + p.i0; }
+          else { mv[n] = (u >= p.T - 1 - p.mirror && u <= p.T - 2 && u >= 0); mb[n] = 2 * (p.T - 1) - u - n0 + p.i0; }
+        }
+        for (int j = 0; j < p.K; ++j) {
+          const float* wj = w_lane + (p.flip ? p.K - 1 - j : j);
+          for (int cs = 0; cs < csteps; ++cs) {
+            float wm_[M_REP], xm_[N_REP];
+#pragma unroll
+            for (int m = 0; m < M_REP; ++m) wm_[m] = wj[m * 16 * p.WS + cs * 4 * p.K];
+#pragma unroll
+            for (int n = 0; n < N_REP; ++n) {
+              const int idx = mb[n] + j * p.d;
+              const bool ok = mv[n] && idx >= 0 && idx < p.span;
+              const float t = xs[(cs * 4 + kq) * p.XS + (ok ? idx : 0)];
+              xm_[n] = ok ? t : 0.f;
+            }
+#pragma unroll
+            for (int m = 0; m < M_REP; ++m)
+#pragma unroll
+              for (int n = 0; n < N_REP; ++n)
+                acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(xm_[n], wm_[m], acc[m][n], 0, 0, 0);
+          }
+        }
+      }
+    }
+  }
+
+  // ---- epilogue: lane owns channel co = .. + ln and time steps t0 .. t0+3 (t0 % 4 == 0, T % 4 == 0)
+#pragma unroll
+  for (int m = 0; m < M_REP; ++m) {
+    const int co = r0 + wrow0 + m * 16 + ln;
+    if (co >= p.Cout) continue;
+    const long ro = (long)co * p.T;
+    float bias = 0.f;
+    if (EPI == EPI_FWD && p.bias) bias = p.bias[co];
+#pragma unroll
+    for (int n = 0; n < N_REP; ++n) {
+      const int t0 = n0 + wcol0 + n * 16 + kq * 4;
+      if (t0 >= p.T) continue;
+      const long oi = ro + t0;
+      f32x4 v = acc[m][n];
+      if (EPI == EPI_FWD) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += bias;
+        if (p.bias3) {
+          const float* k3 = p.bias3 + ((long)b * p.Cout + co) * 3;
+          const float mid = k3[1];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] += mid;
+          if (t0 == 0) v[0] += k3[0] - mid;
+          if (t0 + 4 == p.T) v[3] += k3[2] - mid;
+        }
+        if (p.res) { const f32x4 r = *reinterpret_cast<const f32x4*>(p.res + (long)b * p.res_bs + oi); v += r; }
+        if (p.post == POST_LRELU) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], v[q] * p.m_slope);
+        } else if (p.post == POST_TANH) {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) v[q] = tanhf(v[q]);
+        }
+        v *= p.out_scale;
+      } else if (EPI == EPI_MASK) {
+        const f32x4 mm = *reinterpret_cast<const f32x4*>(p.mx + (long)b * p.mx_bs + oi);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = mm[q] > 0.f ? v[q] : v[q] * p.m_slope;
+      } else if (EPI == EPI_FILM) {
+        const f32x4 h = *reinterpret_cast<const f32x4*>(p.mx + (long)b * p.mx_bs + oi);
+        const float* gp = p.gb + (long)b * p.gb_bs + oi;
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(gp);
+        const f32x4 be = *reinterpret_cast<const f32x4*>(gp + (long)p.Cout * p.T);
+        f32x4 dga, dbe;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const float h2 = h[q] * (1.f + ga[q]) + be[q];
+          const float dh2 = h2 > 0.f ? v[q] : v[q] * p.m_slope;
+          dga[q] = dh2 * h[q]; dbe[q] = dh2; v[q] = dh2 * (1.f + ga[q]);
+        }
+        float* dg = p.dgb + (long)b * p.dgb_bs + oi;
+        *reinterpret_cast<f32x4*>(dg) = dga;
+        *reinterpret_cast<f32x4*>(dg + (long)p.Cout * p.T) = dbe;
+      }
+      if (p.add) { const f32x4 a4 = *reinterpret_cast<const f32x4*>(p.add + (long)b * p.add_bs + oi); v += a4 * p.add_scale; }
+      *reinterpret_cast<f32x4*>(p.y + (long)b * p.y_bs + oi) = v;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------ host
+template <typename K> static inline void lean_big_lds(K k) {
+  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
+}
+
+template <int M_REP, int N_REP, int WM, int WN, int XFK, int EPI>
+static hipError_t lean_launch3(const LeanP& p, int B, hipStream_t st) {
+  constexpr int MT = 16 * M_REP * WM, NT = 16 * N_REP * WN;
+  auto k = conv_lean_kernel<M_REP, N_REP, WM, WN, XFK, EPI>;
+  static bool once = false;
+  if (!once) { lean_big_lds(k); once = true; }
+  dim3 grid((p.T + NT - 1) / NT, (p.Cout + MT - 1) / MT, B);
+  const size_t lds = (size_t)(p.Cc * p.XS + MT * p.WS) * sizeof(float);
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
+  return hipGetLastError();
+}
+
+template <int M_REP, int N_REP, int WM, int WN>
+static hipError_t lean_launch2(const LeanP& p, int B, int xfk, int epi, hipStream_t st) {
+  // the (prologue, epilogue) pairs the train step actually uses; anything else goes to the generic kernel
+  if (xfk == LXF_ACT && epi == EPI_FWD) return lean_launch3<M_REP, N_REP, WM, WN, LXF_ACT, EPI_FWD>(p, B, st);
+  if (xfk == LXF_FILM && epi == EPI_FWD) return lean_launch3<M_REP, N_REP, WM, WN, LXF_FILM, EPI_FWD>(p, B, st);
+  if (xfk == LXF_ACT && epi == EPI_MASK) return lean_launch3<M_REP, N_REP, WM, WN, LXF_ACT, EPI_MASK>(p, B, st);
+  if (xfk == LXF_ACT && epi == EPI_FILM) return lean_launch3<M_REP, N_REP, WM, WN, LXF_ACT, EPI_FILM>(p, B, st);
+  if (xfk == LXF_ACT && epi == EPI_PLAIN) return lean_launch3<M_REP, N_REP, WM, WN, LXF_ACT, EPI_PLAIN>(p, B, st);
+  if (xfk == LXF_MASK_LRELU && epi == EPI_PLAIN) return lean_launch3<M_REP, N_REP, WM, WN, LXF_MASK_LRELU, EPI_PLAIN>(p, B, st);
+  return hipErrorNotSupported;
+}
+
+// Returns hipErrorNotSupported when the shape/variant is outside the lean kernel's contract.
+hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st) {
+  const bool combo = (xfk == LXF_ACT) || (xfk == LXF_FILM && epi == EPI_FWD) || (xfk == LXF_MASK_LRELU && epi == EPI_PLAIN);
+  if (!combo) return hipErrorNotSupported;
+  int MT, NT, cfg;
+  const int R = p.Cout;
+  if (p.T <= 80) { if (R <= 16) { cfg = 3; MT = 16; NT = 64; } else { cfg = 4; MT = 64; NT = 64; } }
+  else if (R <= 16) { cfg = 0; MT = 16; NT = 256; }
+  else if (R <= 32) { cfg = 1; MT = 32; NT = 256; }
+  else { cfg = 2; MT = 64; NT = 256; }
+  const int first = -p.pad;
+  int lo = -p.pad - p.mirror;
+  lo = -(((-lo) + 3) / 4 * 4);
+  const int hi = (p.K - 1) * p.d - p.pad + p.mirror;
+  p.lo = lo; p.i0 = first - lo;
+  p.span = ((NT + hi - lo) + 3) / 4 * 4;
+  p.XS = ((p.span + 31) / 32) * 32 + 16;
+  const int xv = (xfk == LXF_ACT) ? (MT >= 64 ? 8 : 6) : 4;
+  const int wvv = MT >= 64 ? 10 : (MT >= 32 ? 6 : 3);
+  int Cc = 4;
+  while (true) {
+    const int next = Cc + 4;
+    if (next > 32 || next > ((p.Cin + 3) / 4) * 4) break;
+    const size_t lds = (size_t)(next * p.XS + MT * (p.K * next + 2)) * 4;
+    if (lds > 64 * 1024) break;
+    if ((xfk == LXF_ACT && (long)next * (p.span >> 2) > xv * 256) || (long)MT * p.K * next > wvv * 1024) break;
+    Cc = next;
+  }
+  if ((long)MT * p.K * Cc > wvv * 1024) return hipErrorNotSupported;      // weight tile would not fit the register prefetch
+  p.Cc = Cc;
+  p.WS = p.K * Cc + 2;
+  switch (cfg) {
+    case 0: return lean_launch2<1, 4, 1, 4>(p, B, xfk, epi, st);
+    case 1: return lean_launch2<2, 4, 1, 4>(p, B, xfk, epi, st);
+    case 2: return lean_launch2<4, 4, 1, 4>(p, B, xfk, epi, st);
+    case 3: return lean_launch2<1, 1, 1, 4>(p, B, xfk, epi, st);
+    default: return lean_launch2<1, 4, 4, 1>(p, B, xfk, epi, st);
+  }
+}
+
+}  // namespace tdvc

@@ -44,7 +44,7 @@ __device__ __forceinline__ float weight_elem(const GemmConvP& p, int g, int row,
   if (row >= p.R || cr >= p.Cred) return 0.f;
   int m = row, c = cr, k;
   if (MODE == MODE_DIRECT) {
-    k = p.tap_flip ? p.K - 1 - j : j;
+    k = j;                                 // a flipped tap order (dgrad) is applied where the MFMA loop reads LDS
   } else if (MODE == MODE_DOWN) {
     c = cr / p.s; int phi = cr - c * p.s;
     k = phi + j * p.s;
@@ -58,8 +58,10 @@ __device__ __forceinline__ float weight_elem(const GemmConvP& p, int g, int row,
 
 // ----------------------------------------------------------------------------------------------
 // Block tile: MT = 16*M_REP*WM rows x NT = 16*N_REP*WN columns, 4 waves arranged WM x WN.
-template <int MODE, int M_REP, int N_REP, int WM, int WN>
-__global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmConvP p) {
+// PIPE: the input prologue is NONE/LeakyReLU, so interior tiles prefetch their rows into registers one chunk
+// ahead; !PIPE: prologues that read a second/third tensor (FiLM, activation-grad masks) stage in batches.
+template <int MODE, int M_REP, int N_REP, int WM, int WN, bool PIPE>
+__global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 3 : 4)) void conv_gemm_kernel(const GemmConvP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int MT = 16 * M_REP * WM;
   constexpr int NT = 16 * N_REP * WN;
@@ -76,7 +78,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmConvP p) {
   const int b = blockIdx.z;
   const int r0 = mt * MT;
   const int Cx_tot = p.groups * p.x.Cg;
-  const int i0 = (MODE == MODE_DIRECT) ? (-p.pad - p.lo) : 0;   // staged index of tap 0 for column n0
+  const int i0 = p.i0;
 
   f32x4 acc[M_REP][N_REP];
 #pragma unroll
@@ -85,7 +87,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmConvP p) {
     for (int n = 0; n < N_REP; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int wcol0 = wn * 16 * N_REP;   // wave's first column inside the block tile
-  const int wrow0 = wm * 16 * M_REP;
+  const int wrow0_l = wm * 16 * M_REP;
 
   // reflect-fold bookkeeping (dgrad of a reflect-padded stride-1 conv): a column u also collects
   // the padded positions -u (1<=u<=mp) and 2(T-1)-u (T-1-mp<=u<=T-2).
@@ -96,16 +98,43 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmConvP p) {
     needR = (c_lo <= p.N - 2) && (c_hi >= p.N - 1 - p.mirror_pad);
   }
 
+  // Software pipeline over channel chunks (cdna_hip_programming.md T14): the global loads of chunk c+1
+  // (input rows and weight rows, both as aligned float4) are issued before the MFMA loop of chunk c and
+  // committed to LDS after it, so HBM/L2 latency hides under the matrix work.
+  constexpr int XV = 8;                    // float4 per thread: input rows
+  constexpr int WVV = MT >= 64 ? 10 : 6;   // float4 per thread: weight rows
+  RegTile<PIPE ? XV : 1> xr;
+  RegTile<WVV> wr;
+  const int jc = p.J * p.Cc;               // LDS weight row: ws[m][c*J + j]
+  const float inv_j = 1.0f / (float)p.J;
+  const bool fast_tile = (MODE != MODE_DOWN) && rows_fast_ok(p.x, n0 + p.lo, p.span);
+  const bool pipelined = PIPE && fast_tile && p.Cc * (p.span >> 2) <= XV * 256;
+  // weights: natural layout (rows contiguous over (c, k)) and 16-byte alignable -> float4 row copies
+  const bool wfast = (MODE == MODE_DIRECT) && p.w_nat && MT * (jc >> 2) <= WVV * 256;
+  const float* xrow0 = p.x.p + (long)b * p.x.bs + (long)(g * p.x.Cg) * p.x.T + (n0 + p.lo);
+  const float* wrow0 = p.w + (long)g * p.w_sg + (long)r0 * p.w_sm;
+  const Xf wxf = {XF_NONE, 0.f, 1.f, nullptr, 0};
+
+  auto x_issue = [&](int c0) {
+    if (PIPE) tile_issue<PIPE ? XV : 1>(xr, xrow0 + (long)c0 * p.x.T, p.x.T, min(p.Cc, p.Cred - c0), p.Cc, p.span, p.span, 0, tid);
+  };
+  auto w_issue = [&](int c0) {
+    tile_issue<WVV>(wr, wrow0 + (long)c0 * p.K, (int)p.w_sm, min(MT, p.R - r0), MT, jc, min(p.Cc, p.Cred - c0) * p.J, 0, tid);
+  };
+  if (pipelined) x_issue(0);
+  if (wfast) w_issue(0);
+
   for (int c0 = 0; c0 < p.Cred; c0 += p.Cc) {
-    __syncthreads();
-    // ---- stage X' chunk
-    if (MODE == MODE_DOWN && p.stage_rows) {
+    __syncthreads();                       // every wave is done reading the previous chunk
+    // ---- X' chunk -> LDS
+    if (pipelined) {
+      tile_commit<PIPE ? XV : 1>(xr, nullptr, nullptr, p.x.xf, xs, p.XS, min(p.Cc, p.Cred - c0), p.Cc, p.span, 0, tid);
+    } else if (MODE == MODE_DOWN && p.stage_rows) {
       // large stride (STFT framing): consecutive reduced rows (c,phi) are consecutive samples in HBM,
       // so lanes run along rows; XS is odd-ish (17 mod 32) so the LDS writes stay conflict-free
       const int tot = p.Cc * p.span;
-      const float inv_cc = 1.0f / (float)p.Cc;
       for (int e = tid; e < tot; e += 256) {
-        const int i = (int)(((float)e + 0.5f) * inv_cc);
+        const int i = (int)(((float)e + 0.5f) * (1.0f / (float)p.Cc));
         const int r = e - i * p.Cc;
         const int cr = c0 + r;
         float v = 0.f;
@@ -115,6 +144,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmConvP p) {
         }
         xs[r * p.XS + i] = v;
       }
+    } else if (!PIPE && fast_tile) {
+      stage_rows_batched<4>(p.x, xs, p.XS, b, g * p.x.Cg + c0, min(p.Cc, p.Cred - c0), p.Cc, n0 + p.lo, p.span, Cx_tot, tid);
     } else {
       for (int r = wave; r < p.Cc; r += 4) {
         const int cr = c0 + r;
@@ -130,30 +161,35 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmConvP p) {
         }
       }
     }
-    // ---- stage A chunk
-    const int jc = p.J * p.Cc;
-    const float inv_cc = 1.0f / (float)p.Cc;
-    for (int m = wave; m < MT; m += 4) {
-      float* row = ws + m * p.WS;
-      for (int idx = lane; idx < jc; idx += 64) {
-        const int j = (int)(((float)idx + 0.5f) * inv_cc);
-        const int c = idx - j * p.Cc;
-        row[idx] = weight_elem<MODE>(p, g, r0 + m, c0 + c, j);
+    // ---- A chunk -> LDS, ws[m][c*J + j]
+    if (wfast) {
+      tile_commit<WVV>(wr, nullptr, nullptr, wxf, ws, p.WS, min(MT, p.R - r0), MT, jc, 0, tid);
+    } else {
+      for (int m = wave; m < MT; m += 4) {
+        float* row = ws + m * p.WS;
+        for (int idx = lane; idx < jc; idx += 64) {
+          const int c = (int)(((float)idx + 0.5f) * inv_j);
+          row[idx] = weight_elem<MODE>(p, g, r0 + m, c0 + c, idx - c * p.J);
+        }
       }
     }
     __syncthreads();
+    if (c0 + p.Cc < p.Cred) {              // next chunk's loads fly while this chunk's MFMAs run
+      if (pipelined) x_issue(c0 + p.Cc);
+      if (wfast) w_issue(c0 + p.Cc);
+    }
 
-    // ---- MFMA main loop: K dimension = (tap j, channel c) with c innermost
+    // ---- MFMA main loop: K dimension = (tap j, channel c); each 16x16x4 step takes 4 channels of one tap
     const int csteps = p.Cc >> 2;
-    const float* a_base = ws + (wrow0 + ln) * p.WS + kq;
+    const float* a_base = ws + (wrow0_l + ln) * p.WS + kq * p.J;
     const float* b_base = xs + kq * p.XS + wcol0 + ln + i0;
     for (int j = 0; j < p.J; ++j) {
-      const float* aj = a_base + j * p.Cc;
+      const float* aj = a_base + (p.tap_flip ? p.J - 1 - j : j);
       const float* bj = b_base + j * p.d;
       for (int cs = 0; cs < csteps; ++cs) {
         float a[M_REP], bv[N_REP];
 #pragma unroll
-        for (int m = 0; m < M_REP; ++m) a[m] = aj[m * 16 * p.WS + cs * 4];
+        for (int m = 0; m < M_REP; ++m) a[m] = aj[m * 16 * p.WS + cs * 4 * p.J];
 #pragma unroll
         for (int n = 0; n < N_REP; ++n) bv[n] = bj[cs * 4 * p.XS + n * 16];
 #pragma unroll
@@ -171,15 +207,15 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmConvP p) {
 #pragma unroll
         for (int n = 0; n < N_REP; ++n) {
           const int u = n0 + wcol0 + n * 16 + ln;
-          if (side == 0) { mv[n] = (u >= 1 && u <= p.mirror_pad && u < p.N); mb[n] = -u - n0 + p.mirror_pad; }
-          else { mv[n] = (u >= p.N - 1 - p.mirror_pad && u <= p.N - 2 && u >= 0); mb[n] = 2 * (p.N - 1) - u - n0 + p.mirror_pad; }
+          if (side == 0) { mv[n] = (u >= 1 && u <= p.mirror_pad && u < p.N); mb[n] = -u - n0 + i0; }
+          else { mv[n] = (u >= p.N - 1 - p.mirror_pad && u <= p.N - 2 && u >= 0); mb[n] = 2 * (p.N - 1) - u - n0 + i0; }
         }
         for (int j = 0; j < p.J; ++j) {
-          const float* aj = a_base + j * p.Cc;
+          const float* aj = a_base + (p.tap_flip ? p.J - 1 - j : j);
           for (int cs = 0; cs < csteps; ++cs) {
             float a[M_REP], bv[N_REP];
 #pragma unroll
-            for (int m = 0; m < M_REP; ++m) a[m] = aj[m * 16 * p.WS + cs * 4];
+            for (int m = 0; m < M_REP; ++m) a[m] = aj[m * 16 * p.WS + cs * 4 * p.J];
 #pragma unroll
             for (int n = 0; n < N_REP; ++n) {
               const int idx = mb[n] + j * p.d;
@@ -208,7 +244,7 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(const GemmConvP p) {
       if (col >= p.N) continue;
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        const int row = r0 + wrow0 + m * 16 + kq * 4 + r;
+        const int row = r0 + wrow0_l + m * 16 + kq * 4 + r;
         if (row >= p.R) continue;
         int ch, u;
         if (MODE == MODE_UP) {
@@ -239,7 +275,7 @@ __global__ __launch_bounds__(256) void conv_scalar_kernel(const GemmConvP p) {
       if (MODE == MODE_DOWN) { int c = cr / p.s; phi = cr - c * p.s; ch = g * p.x.Cg + c; }
       else ch = g * p.x.Cg + cr;
       for (int j = 0; j < p.J; ++j) {
-        const float wv = weight_elem<MODE>(p, g, row, cr, j);
+        const float wv = weight_elem<MODE>(p, g, row, cr, (MODE == MODE_DIRECT && p.tap_flip) ? p.J - 1 - j : j);
         int xi;
         if (MODE == MODE_DIRECT) xi = col + j * p.d - p.pad;
         else if (MODE == MODE_DOWN) xi = col + j;
@@ -270,7 +306,7 @@ __global__ __launch_bounds__(256) void conv_scalar_kernel(const GemmConvP p) {
 // (row tile, 16-channel tile) x (time chunk, batch group); the 4 waves split the time chunk and
 // are summed through LDS; the block writes its partial into a slab (no atomics: deterministic).
 template <int MODE, int M_REP, int J>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p, int bpb, int B) {
+__global__ __launch_bounds__(256, (M_REP * J >= 14 ? 3 : 4)) void conv_wgrad_kernel(const WgradP p, int bpb, int B) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int MT = 16 * M_REP;
   constexpr int E = M_REP * J * 4;
@@ -287,7 +323,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p, int bpb
   const int nc0 = tile * p.NTc;
   const int r0 = mt * MT, c0 = ct * 16;
   const int Ca_tot = p.groups * p.a.Cg, Cx_tot = p.groups * p.x.Cg;
-  const int i0 = (MODE == MODE_DIRECT) ? (-p.pad - p.lo) : 0;
+  const int i0 = p.i0;
 
   f32x4 acc[M_REP][J];
 #pragma unroll
@@ -298,26 +334,34 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgradP p, int bpb
   const int b_lo = bg * bpb, b_hi = min(B, b_lo + bpb);
   for (int b = b_lo; b < b_hi; ++b) {
     __syncthreads();
-    for (int m = wave; m < MT; m += 4) {
-      const int row = r0 + m;
-      const int ch = g * p.a.Cg + row;
-      float* dst = as + m * p.AS;
-      for (int i = lane; i < p.NTc; i += 64) {
-        const int n = nc0 + i;
-        dst[i] = (row < p.R && n < p.N) ? fetch_opnd(p.a, b, ch, n, 0, Ca_tot) : 0.f;
+    if (nc0 + p.NTc <= p.N && rows_fast_ok(p.a, nc0, p.NTc)) {
+      stage_rows_batched<8>(p.a, as, p.AS, b, g * p.a.Cg + r0, min(MT, p.R - r0), MT, nc0, p.NTc, Ca_tot, tid);
+    } else {
+      for (int m = wave; m < MT; m += 4) {
+        const int row = r0 + m;
+        const int ch = g * p.a.Cg + row;
+        float* dst = as + m * p.AS;
+        for (int i = lane; i < p.NTc; i += 64) {
+          const int n = nc0 + i;
+          dst[i] = (row < p.R && n < p.N) ? fetch_opnd(p.a, b, ch, n, 0, Ca_tot) : 0.f;
+        }
       }
     }
-    for (int r = wave; r < 16; r += 4) {
-      const int cr = c0 + r;
-      const bool rv = cr < p.Cred;
-      int ch, phi = 0;
-      if (MODE == MODE_DOWN) { int c = cr / p.s; phi = cr - c * p.s; ch = g * p.x.Cg + c; }
-      else ch = g * p.x.Cg + cr;
-      float* dst = xs + r * p.XS;
-      for (int i = lane; i < p.span; i += 64) {
-        const int xi = nc0 + p.lo + i;
-        const int q = (MODE == MODE_DOWN) ? xi * p.s + phi - p.pad : xi;
-        dst[i] = rv ? fetch_opnd(p.x, b, ch, q, p.reflect, Cx_tot) : 0.f;
+    if (MODE != MODE_DOWN && rows_fast_ok(p.x, nc0 + p.lo, p.span)) {
+      stage_rows_batched<8>(p.x, xs, p.XS, b, g * p.x.Cg + c0, min(16, p.Cred - c0), 16, nc0 + p.lo, p.span, Cx_tot, tid);
+    } else {
+      for (int r = wave; r < 16; r += 4) {
+        const int cr = c0 + r;
+        const bool rv = cr < p.Cred;
+        int ch, phi = 0;
+        if (MODE == MODE_DOWN) { int c = cr / p.s; phi = cr - c * p.s; ch = g * p.x.Cg + c; }
+        else ch = g * p.x.Cg + cr;
+        float* dst = xs + r * p.XS;
+        for (int i = lane; i < p.span; i += 64) {
+          const int xi = nc0 + p.lo + i;
+          const int q = (MODE == MODE_DOWN) ? xi * p.s + phi - p.pad : xi;
+          dst[i] = rv ? fetch_opnd(p.x, b, ch, q, p.reflect, Cx_tot) : 0.f;
+        }
       }
     }
     __syncthreads();
@@ -433,16 +477,22 @@ static inline void allow_big_lds(KernelT k) {
   hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
 
-template <int MODE, int M_REP, int N_REP, int WM, int WN>
-static hipError_t launch_gemm_cfg(const GemmConvP& p, int B, hipStream_t st) {
+template <int MODE, int M_REP, int N_REP, int WM, int WN, bool PIPE>
+static hipError_t launch_gemm_cfg2(const GemmConvP& p, int B, hipStream_t st) {
   constexpr int MT = 16 * M_REP * WM, NT = 16 * N_REP * WN;
-  auto k = conv_gemm_kernel<MODE, M_REP, N_REP, WM, WN>;
+  auto k = conv_gemm_kernel<MODE, M_REP, N_REP, WM, WN, PIPE>;
   static bool once = false;
   if (!once) { allow_big_lds(k); once = true; }
   dim3 grid((p.N + NT - 1) / NT, p.groups * ((p.R + MT - 1) / MT), B);
   size_t lds = (size_t)(p.Cc * p.XS + MT * p.WS) * sizeof(float);
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
   return hipGetLastError();
+}
+
+template <int MODE, int M_REP, int N_REP, int WM, int WN>
+static hipError_t launch_gemm_cfg(const GemmConvP& p, int B, hipStream_t st) {
+  if (p.x.xf.kind <= XF_LRELU) return launch_gemm_cfg2<MODE, M_REP, N_REP, WM, WN, true>(p, B, st);
+  return launch_gemm_cfg2<MODE, M_REP, N_REP, WM, WN, false>(p, B, st);
 }
 
 // Tile shape selection; fills the LDS geometry (Cc, span, XS, WS) for the chosen NT/MT.
@@ -454,8 +504,12 @@ hipError_t launch_conv_gemm(GemmConvP p, int B, hipStream_t st) {
   else if (p.R <= 32) { cfg = 1; MT = 32; NT = 256; }
   else { cfg = 2; MT = 64; NT = 256; }
   const int hi = (MODE == MODE_DIRECT) ? (p.J - 1) * p.d - p.pad + p.mirror_pad : (MODE == MODE_DOWN ? p.J - 1 : 0);
-  p.lo = (MODE == MODE_DIRECT) ? -p.pad - p.mirror_pad : (MODE == MODE_DOWN ? 0 : -(p.J - 1));
-  p.span = NT + hi - p.lo;
+  const int first = (MODE == MODE_DIRECT) ? -p.pad : (MODE == MODE_DOWN ? 0 : -(p.J - 1));   // position read by column 0, tap 0
+  int lo = (MODE == MODE_DIRECT) ? -p.pad - p.mirror_pad : first;
+  lo = -(((-lo) + 3) / 4 * 4);              // tile origins are multiples of 4: keeps interior tiles float4-aligned
+  p.lo = lo;
+  p.i0 = first - lo;
+  p.span = ((NT + hi - lo) + 3) / 4 * 4;
   p.XS = ((p.span + 31) / 32) * 32 + 16;   // == 16 (mod 32): the two k-rows of a 32-lane group hit disjoint banks
   // channel chunk: multiple of 4, sized so that LDS stays <= ~60 KB (>= 2 blocks per CU)
   const int unit = 4;
@@ -467,10 +521,14 @@ hipError_t launch_conv_gemm(GemmConvP p, int B, hipStream_t st) {
     if (next > 32 || next > ((p.Cred + unit - 1) / unit) * unit) break;
     size_t lds = (size_t)(next * p.XS + MT * (p.J * next + 2)) * 4;
     if (lds > 60 * 1024) break;
+    // keep the chunk inside the kernels' register-prefetch budgets (8 float4 of input, 24/36 weights per thread)
+    if (Cc >= 8 && ((long)next * (p.span >> 2) > 8 * 256 || (long)MT * p.J * next > (MT >= 64 ? 10 : 6) * 1024)) break;
     Cc = next;
   }
   p.Cc = Cc;
-  p.WS = p.J * Cc + 2;                      // WS/2 odd: 16 rows x 2 k-lanes hit 32 distinct banks
+  p.WS = p.J * Cc + 2;                      // WS/2 odd: 16 rows x 2 k-lanes hit 32 distinct banks (odd J)
+  p.w_nat = (MODE == MODE_DIRECT && p.w_sc == p.K && (p.w_sm & 3) == 0 && (p.w_sg & 3) == 0 && (p.Cred & 3) == 0 &&
+             (((uintptr_t)p.w) & 15) == 0) ? 1 : 0;
   switch (cfg) {
     case 0: return launch_gemm_cfg<MODE, 1, 4, 1, 4>(p, B, st);
     case 1: return launch_gemm_cfg<MODE, 2, 4, 1, 4>(p, B, st);
@@ -537,9 +595,11 @@ int wgrad_geometry(WgradP& p, int B, int* bpb_out) {
   p.NTc = NTc;
   p.ntiles = (p.N + NTc - 1) / NTc;
   const int hi = direct ? (p.J - 1) * p.d - p.pad : p.J - 1;
-  p.lo = direct ? -p.pad : 0;
-  p.span = NTc + hi - p.lo;
-  p.XS = ((p.span + 31) / 32) * 32 + 2;
+  const int first = direct ? -p.pad : 0;
+  p.lo = -(((-first) + 3) / 4 * 4);
+  p.i0 = first - p.lo;
+  p.span = ((NTc + hi - p.lo) + 3) / 4 * 4;
+  p.XS = ((p.span + 31) / 32) * 32 + 2;     // 2 (mod 32): 16 rows x 2 k-lanes hit 32 distinct banks
   p.AS = ((NTc + 31) / 32) * 32 + 2;
   // short sequences: loop the whole batch inside one block so that only one slab is written
   int bpb = (p.N <= 128) ? B : 1;

@@ -38,7 +38,9 @@ __device__ __forceinline__ float block_sum(float v, float* sh /* >= 4 floats */)
 // one wave per weight row (dim-0 slice); rows of all tensors of a model in one launch
 __global__ __launch_bounds__(256) void wn_fwd_kernel(const float* __restrict__ params, float* __restrict__ w,
                                                      const int64_t* row_voff, const int64_t* row_goff,
-                                                     const int64_t* row_woff, const int32_t* row_len, int nrows) {
+                                                     const int64_t* row_woff, const int32_t* row_len, int nrows,
+                                                     float* __restrict__ wt, const int64_t* row_tbase,
+                                                     const int64_t* row_tstride, const int32_t* row_k) {
   const int row = blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= nrows) return;
   const int lane = threadIdx.x & 63;
@@ -49,7 +51,19 @@ __global__ __launch_bounds__(256) void wn_fwd_kernel(const float* __restrict__ p
   for (int i = lane; i < n; i += 64) { float t = v[i]; ss += t * t; }
   ss = wave_sum(ss);
   const float sc = params[row_goff[row]] / sqrtf(ss);
-  for (int i = lane; i < n; i += 64) o[i] = v[i] * sc;
+  const int K = wt ? row_k[row] : 0;
+  if (K > 0) {
+    float* tb = wt + row_tbase[row];
+    const long ts = row_tstride[row];
+    for (int i = lane; i < n; i += 64) {
+      const float val = v[i] * sc;
+      o[i] = val;
+      const int ci = i / K;
+      tb[(long)ci * ts + (i - ci * K)] = val;
+    }
+  } else {
+    for (int i = lane; i < n; i += 64) o[i] = v[i] * sc;
+  }
 }
 
 __global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ params, const float* __restrict__ dw,
@@ -397,7 +411,17 @@ __global__ __launch_bounds__(128) void contrastive_kernel(const float* X, const 
 extern "C" int tdvc_weight_norm_fwd(const float* params, float* w, const int64_t* row_voff, const int64_t* row_goff,
                                     const int64_t* row_woff, const int32_t* row_len, int nrows, void* stream) {
   if (!params || !w || nrows <= 0) return tdvc_fail(TDVC_EINVAL, "weight_norm_fwd: bad arguments");
-  hipLaunchKernelGGL(wn_fwd_kernel, dim3((nrows + 3) / 4), dim3(256), 0, (hipStream_t)stream, params, w, row_voff, row_goff, row_woff, row_len, nrows);
+  hipLaunchKernelGGL(wn_fwd_kernel, dim3((nrows + 3) / 4), dim3(256), 0, (hipStream_t)stream, params, w, row_voff, row_goff, row_woff, row_len, nrows,
+                     (float*)nullptr, (const int64_t*)nullptr, (const int64_t*)nullptr, (const int32_t*)nullptr);
+  TDVC_CHECK_LAUNCH();
+  return TDVC_OK;
+}
+extern "C" int tdvc_weight_norm_fwd_t(const float* params, float* w, float* wt, const int64_t* row_voff, const int64_t* row_goff,
+                                      const int64_t* row_woff, const int32_t* row_len, const int64_t* row_tbase,
+                                      const int64_t* row_tstride, const int32_t* row_k, int nrows, void* stream) {
+  if (!params || !w || !wt || nrows <= 0) return tdvc_fail(TDVC_EINVAL, "weight_norm_fwd_t: bad arguments");
+  hipLaunchKernelGGL(wn_fwd_kernel, dim3((nrows + 3) / 4), dim3(256), 0, (hipStream_t)stream, params, w, row_voff, row_goff, row_woff, row_len, nrows,
+                     wt, row_tbase, row_tstride, row_k);
   TDVC_CHECK_LAUNCH();
   return TDVC_OK;
 }

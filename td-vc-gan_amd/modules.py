@@ -127,7 +127,9 @@ class ArenaModule(nn.Module):
         if self._arena is not None and self._arena.device == device and self._arena.owns(ps[0]) and self._arena.owns(ps[-1]):
             return self._arena
         L.lib()   # fail loudly before touching anything if the extension is missing
-        self._arena = ParamArena(self, device, self.dead_prefixes)
+        tr = [name for name, m in self.named_modules()
+              if isinstance(m, ConvParams) and m.wn and m.spec.kind == L.CONV and m.spec.stride == 1 and m.spec.groups == 1]
+        self._arena = ParamArena(self, device, self.dead_prefixes, transposable=tr)
         for name, m in self.named_modules():
             if isinstance(m, (ConvParams, LinearParams)):
                 if any((name + '.').startswith(d) for d in self.dead_prefixes):
@@ -173,7 +175,7 @@ class FiLMResnetBlock(nn.Module):
         if self.has_cond and self.cond_var[0].spec.slot is not None:
             s = self.cond_var[0].spec.slot
             self.spec_const.slot = s                                             # carries the bias
-            self.spec_var.slot = ConvSlot(s.w, 0, s.dw, 0, s.trainable, s.arena)  # no bias on the time-varying part
+            self.spec_var.slot = ConvSlot(s.w, 0, s.dw, 0, s.trainable, s.arena, s.wt)  # no bias on the time-varying part
 
     def forward(self, x, c=None, acc=None, scale=1.0):
         """c: None (encoder), a dense [B,n_const+n_var,T] conditioning tensor (reference formulation), or a

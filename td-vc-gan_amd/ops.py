@@ -98,7 +98,7 @@ def conv_dgrad_raw(spec: ConvSpec, dy, dy_xf, tin, epilogue=L.DG_PLAIN, x_in=Non
     d = spec.desc(B, tin)
     dx = out if out is not None else torch.empty((B, spec.cin, tin), dtype=torch.float32, device=dy.device)
     _check_layout(dy); _check_layout(dx)
-    a = L.ConvDgradArgs(dy.data_ptr(), _bs(dy), dy_xf, spec.slot.w, epilogue,
+    a = L.ConvDgradArgs(dy.data_ptr(), _bs(dy), dy_xf, spec.slot.w, spec.slot.wt or None, epilogue,
                         x_in.data_ptr() if x_in is not None else None, _bs(x_in) if x_in is not None else 0, SLOPE,
                         gb.data_ptr() if gb is not None else None, _bs(gb) if gb is not None else 0,
                         dgb.data_ptr() if dgb is not None else None, _bs(dgb) if dgb is not None else 0,

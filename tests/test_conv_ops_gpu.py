@@ -95,7 +95,8 @@ def test_conv_fwd_bwd(case, generic, dev):
 
     wd, bd = w.float().to(dev).contiguous(), b.float().to(dev).contiguous()
     dw, db = torch.zeros_like(wd), torch.zeros_like(bd)
-    spec.slot = arena.ConvSlot(wd.data_ptr(), bd.data_ptr(), dw.data_ptr(), db.data_ptr(), True, None)
+    wt = wd.permute(1, 0, 2).contiguous() if (not transposed and g == 1 and s == 1) else None   # [Cin][Cout][K] copy for the lean dgrad
+    spec.slot = arena.ConvSlot(wd.data_ptr(), bd.data_ptr(), dw.data_ptr(), db.data_ptr(), True, None, wt.data_ptr() if wt is not None else 0)
     L.lib().tdvc_set_force_generic(generic)
     try:
         xd = x.float().to(dev).requires_grad_(True)
@@ -145,8 +146,9 @@ def test_film_block(cfg, dev):
     grads = {n: torch.zeros_like(t) for n, t in dts.items()}
     cs = ops.ConvSpec(C, C, k, 1, pad, d, 1, True)
     ps = ops.ConvSpec(C, C, 1)
-    cs.slot = arena.ConvSlot(dts['w1'].data_ptr(), dts['b1'].data_ptr(), grads['w1'].data_ptr(), grads['b1'].data_ptr(), True, None)
-    ps.slot = arena.ConvSlot(dts['w2'].data_ptr(), dts['b2'].data_ptr(), grads['w2'].data_ptr(), grads['b2'].data_ptr(), True, None)
+    w1t, w2t = dts['w1'].permute(1, 0, 2).contiguous(), dts['w2'].permute(1, 0, 2).contiguous()
+    cs.slot = arena.ConvSlot(dts['w1'].data_ptr(), dts['b1'].data_ptr(), grads['w1'].data_ptr(), grads['b1'].data_ptr(), True, None, w1t.data_ptr())
+    ps.slot = arena.ConvSlot(dts['w2'].data_ptr(), dts['b2'].data_ptr(), grads['w2'].data_ptr(), grads['b2'].data_ptr(), True, None, w2t.data_ptr())
     xd = f(x).requires_grad_(True)
     gbd = f(gb).requires_grad_(True) if cond else None
     accd = f(acc).requires_grad_(True) if with_acc else None

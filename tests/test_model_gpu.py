@@ -52,7 +52,8 @@ def test_generator_forward_backward_vs_golden(models, dev, tag, seed):
         samp = p.grad.reshape(-1)[torch.tensor(idx, device=dev)].double().cpu()
         e_norm = abs(n - n_ref) / (n_ref + 1e-30)
         e_samp = float((samp - torch.tensor(vals)).norm()) / (n_ref / max(1.0, p.numel() ** 0.5) * 2 + 1e-30)
-        if e_norm > TOL or e_samp > 0.05:
+        tol = max(TOL, 5.0 * gg.get('noise', {}).get(k, 0.0))    # fp32 noise floor of this tensor (oracle fp32 vs fp64)
+        if e_norm > tol or e_samp > 0.05:
             bad[k] = (e_norm, e_samp)
     assert not bad, dict(list(bad.items())[:8])
 
@@ -113,7 +114,7 @@ def test_discriminator_vs_golden(models, dev, tag, seed):
     for k, p in D.named_parameters():
         n_ref = gj['norms'][k]
         e = abs(float(p.grad.double().norm()) - n_ref) / (n_ref + 1e-30)
-        if e > TOL:
+        if e > max(TOL, 5.0 * gj.get('noise', {}).get(k, 0.0)):
             bad[k] = e
     assert not bad, bad
 
