@@ -26,6 +26,7 @@ struct LeanP {
   int T, Cin, Cout, Cw, K, d, pad, flip, reflect, mirror;
   int Cc, span, lo, i0, XS, WS;
   int post;
+  int vec;
   float slope, in_scale, out_scale, add_scale, m_slope;
 };
 hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st);
@@ -34,7 +35,8 @@ hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st);
 using namespace tdvc;
 
 static inline bool al16(const void* p) { return (((uintptr_t)p) & 15) == 0; }
-static inline bool ok_bs(const void* p, long bs) { return !p || (al16(p) && (bs & 3) == 0 && bs < (1L << 31)); }
+static inline bool ok_bs(const void* p, long bs) { return !p || (bs < (1L << 31)); }
+static inline bool vec_ptr(const void* p, long bs) { return !p || (al16(p) && (bs & 3) == 0); }
 
 // Prologue kind of the lean kernel for an operand transform; -1 = not supported there.
 static int lean_xfk(const tdvc_xform& x, float* slope, float* scale, const float** aux, long* aux_bs) {
@@ -50,7 +52,7 @@ static int lean_xfk(const tdvc_xform& x, float* slope, float* scale, const float
 }
 
 static bool lean_shape_ok(const tdvc_conv_desc* d) {
-  return d->kind == TDVC_CONV && d->stride == 1 && d->groups == 1 && d->Tin == d->Tout && (d->Tin & 3) == 0;
+  return d->kind == TDVC_CONV && d->stride == 1 && d->groups == 1 && d->Tin == d->Tout && ((d->Tin & 3) == 0 || d->Tin <= 80);
 }
 
 static int g_force_generic = 0;
@@ -125,11 +127,15 @@ extern "C" int tdvc_conv_fwd(const tdvc_conv_desc* d, const tdvc_conv_fwd_args* 
       q.T = d->Tin; q.Cin = d->Cin; q.Cout = d->Cout; q.Cw = cw; q.K = d->K; q.d = d->dilation; q.pad = d->pad; q.reflect = d->reflect;
       q.post = a->post_act; q.slope = slope; q.in_scale = scale; q.out_scale = a->out_scale == 0.f ? 1.f : a->out_scale;
       q.add_scale = 1.f; q.m_slope = a->post_slope;
+      q.vec = ((d->Tin & 3) == 0 && vec_ptr(a->x, a->x_bs) && vec_ptr(a->y, a->y_bs) && vec_ptr(a->res, a->res_bs) &&
+               vec_ptr(a->add, a->add_bs) && vec_ptr(aux, aux_bs)) ? 1 : 0;
+      if (!q.vec && d->Tin > 80) goto generic_fwd;
       hipError_t e = launch_conv_lean(q, d->B, xfk, EPI_FWD, (hipStream_t)stream);
       if (e == hipSuccess) return TDVC_OK;
       if (e != hipErrorNotSupported) return tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));
     }
   }
+generic_fwd:
   GemmConvP p = {};
   p.x.p = a->x; p.x.bs = a->x_bs; p.x.T = d->Tin; p.x.Cg = Cin_g; p.x.xf = to_xf(a->x_xf);
   p.w = a->w; p.K = d->K; p.s = d->stride; p.pad = d->pad; p.groups = d->groups;
@@ -172,11 +178,15 @@ extern "C" int tdvc_conv_dgrad(const tdvc_conv_desc* d, const tdvc_conv_dgrad_ar
       q.T = d->Tin; q.Cin = d->Cout; q.Cout = d->Cin; q.Cw = cw; q.K = d->K; q.d = d->dilation;
       q.pad = (d->K - 1) * d->dilation - d->pad; q.flip = 1; q.mirror = d->reflect ? d->pad : 0;
       q.slope = slope; q.in_scale = scale; q.out_scale = 1.f; q.add_scale = a->add_scale; q.m_slope = a->slope;
+      q.vec = ((d->Tin & 3) == 0 && vec_ptr(a->dy, a->dy_bs) && vec_ptr(a->dx, a->dx_bs) && vec_ptr(a->add, a->add_bs) && vec_ptr(aux, aux_bs) &&
+               vec_ptr(a->x_in, a->x_in_bs) && vec_ptr(a->gb, a->gb_bs) && vec_ptr(a->dgb, a->dgb_bs)) ? 1 : 0;
+      if (!q.vec && d->Tin > 80) goto generic_dgrad;
       hipError_t e = launch_conv_lean(q, d->B, xfk, epi, (hipStream_t)stream);
       if (e == hipSuccess) return TDVC_OK;
       if (e != hipErrorNotSupported) return tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));
     }
   }
+generic_dgrad:
   GemmConvP p = {};
   p.x.p = a->dy; p.x.bs = a->dy_bs; p.x.T = d->Tout; p.x.Cg = Cout_g; p.x.xf = to_xf(a->dy_xf);
   p.w = a->w; p.K = d->K; p.s = d->stride; p.groups = d->groups;

@@ -26,6 +26,7 @@ struct LeanP {
   int T, Cin, Cout, Cw, K, d, pad, flip, reflect, mirror;
   int Cc, span, lo, i0, XS, WS;
   int post;
+  int vec;                             // host-checked: T % 4 == 0, every pointer 16-byte aligned, batch strides % 4 == 0
   float slope, in_scale, out_scale, add_scale, m_slope;
 };
 
@@ -52,8 +53,8 @@ template <int M_REP, int N_REP, int WM, int WN, int XFK, int EPI>
 __global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 2 : (M_REP * N_REP >= 8 ? 3 : 4))) void conv_lean_kernel(const LeanP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int MT = 16 * M_REP * WM, NT = 16 * N_REP * WN;
-  constexpr int XV = (XFK == LXF_ACT) ? (MT >= 64 ? 8 : 6) : 4;      // float4 per thread per staged tensor
-  constexpr int WVV = MT >= 64 ? 10 : (MT >= 32 ? 6 : 3);
+  constexpr int XV = (XFK == LXF_ACT) ? (MT >= 48 ? 8 : 6) : 4;      // float4 per thread per staged tensor
+  constexpr int WVV = MT >= 48 ? 10 : (MT >= 32 ? 6 : 3);
   float* xs = smem;
   float* ws = smem + p.Cc * p.XS;
 
@@ -70,7 +71,8 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 2 : (M_REP * N_REP >= 8
     for (int n = 0; n < N_REP; ++n) acc[m][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   const int q0 = n0 + p.lo;
-  const bool interior = q0 >= 0 && q0 + p.span <= p.T;
+  const bool vec_ok = p.vec != 0;                      // rows 16-byte aligned -> float4 staging / epilogue
+  const bool interior = vec_ok && q0 >= 0 && q0 + p.span <= p.T;
   const int jc = p.K * p.Cc;
   const float* xrow0 = p.x + (long)b * p.x_bs + q0;
   const float* arow0 = (XFK != LXF_ACT) ? p.aux + (long)b * p.aux_bs + q0 : nullptr;
@@ -198,6 +200,46 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 2 : (M_REP * N_REP >= 8
   }
 
   // ---- epilogue: lane owns channel co = .. + ln and time steps t0 .. t0+3 (t0 % 4 == 0, T % 4 == 0)
+  if (!vec_ok) {   // short, unaligned sequences (T = 50, 63): scalar epilogue
+#pragma unroll
+    for (int m = 0; m < M_REP; ++m) {
+      const int co = r0 + wrow0 + m * 16 + ln;
+      if (co >= p.Cout) continue;
+      const long ro = (long)co * p.T;
+      const float bias = (EPI == EPI_FWD && p.bias) ? p.bias[co] : 0.f;
+#pragma unroll
+      for (int n = 0; n < N_REP; ++n) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int t = n0 + wcol0 + n * 16 + kq * 4 + q;
+          if (t >= p.T) continue;
+          const long oi = ro + t;
+          float v = acc[m][n][q];
+          if (EPI == EPI_FWD) {
+            v += bias;
+            if (p.bias3) v += p.bias3[((long)b * p.Cout + co) * 3 + (t == 0 ? 0 : (t == p.T - 1 ? 2 : 1))];
+            if (p.res) v += p.res[(long)b * p.res_bs + oi];
+            if (p.post == POST_LRELU) v = fmaxf(v, v * p.m_slope);
+            else if (p.post == POST_TANH) v = tanhf(v);
+            v *= p.out_scale;
+          } else if (EPI == EPI_MASK) {
+            v = p.mx[(long)b * p.mx_bs + oi] > 0.f ? v : v * p.m_slope;
+          } else if (EPI == EPI_FILM) {
+            const float h = p.mx[(long)b * p.mx_bs + oi];
+            const float* gp = p.gb + (long)b * p.gb_bs + oi;
+            const float ga = gp[0], be = gp[(long)p.Cout * p.T];
+            const float dh2 = (h * (1.f + ga) + be) > 0.f ? v : v * p.m_slope;
+            float* dg = p.dgb + (long)b * p.dgb_bs + oi;
+            dg[0] = dh2 * h; dg[(long)p.Cout * p.T] = dh2;
+            v = dh2 * (1.f + ga);
+          }
+          if (p.add) v += p.add_scale * p.add[(long)b * p.add_bs + oi];
+          p.y[(long)b * p.y_bs + oi] = v;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int m = 0; m < M_REP; ++m) {
     const int co = r0 + wrow0 + m * 16 + ln;
@@ -290,12 +332,21 @@ static hipError_t lean_launch2(const LeanP& p, int B, int xfk, int epi, hipStrea
 hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st) {
   const bool combo = (xfk == LXF_ACT) || (xfk == LXF_FILM && epi == EPI_FWD) || (xfk == LXF_MASK_LRELU && epi == EPI_PLAIN);
   if (!combo) return hipErrorNotSupported;
-  int MT, NT, cfg;
+  // Tile choice: the largest tile whose grid still covers the chip ~2x (256 CUs), else the smallest one.
+  struct Cand { int MT, NT, cfg; };
+  static const Cand cands[] = {{64, 256, 2}, {48, 256, 5}, {32, 256, 1}, {64, 64, 4}, {32, 64, 6}, {16, 256, 0}, {16, 64, 3}};
   const int R = p.Cout;
-  if (p.T <= 80) { if (R <= 16) { cfg = 3; MT = 16; NT = 64; } else { cfg = 4; MT = 64; NT = 64; } }
-  else if (R <= 16) { cfg = 0; MT = 16; NT = 256; }
-  else if (R <= 32) { cfg = 1; MT = 32; NT = 256; }
-  else { cfg = 2; MT = 64; NT = 256; }
+  int MT = 16, NT = 64, cfg = 3;
+  for (const Cand& c : cands) {
+    if (c.MT > 16 && R <= 16) continue;
+    if (c.MT > 32 && R <= 32) continue;
+    if (c.MT == 48 && !(R % 64 != 0 && (R + 47) / 48 * 48 < (R + 63) / 64 * 64)) continue;
+    if (c.MT == 64 && c.NT == 256 && (R % 64 != 0 && (R + 47) / 48 * 48 < (R + 63) / 64 * 64)) continue;
+    if (c.NT == 256 && p.T <= 80) continue;
+    const long blocks = (long)((R + c.MT - 1) / c.MT) * ((p.T + c.NT - 1) / c.NT) * B;
+    MT = c.MT; NT = c.NT; cfg = c.cfg;
+    if (blocks >= 512) break;
+  }
   const int first = -p.pad;
   int lo = -p.pad - p.mirror;
   lo = -(((-lo) + 3) / 4 * 4);
@@ -303,8 +354,8 @@ hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st) {
   p.lo = lo; p.i0 = first - lo;
   p.span = ((NT + hi - lo) + 3) / 4 * 4;
   p.XS = ((p.span + 31) / 32) * 32 + 16;
-  const int xv = (xfk == LXF_ACT) ? (MT >= 64 ? 8 : 6) : 4;
-  const int wvv = MT >= 64 ? 10 : (MT >= 32 ? 6 : 3);
+  const int xv = (xfk == LXF_ACT) ? (MT >= 48 ? 8 : 6) : 4;
+  const int wvv = MT >= 48 ? 10 : (MT >= 32 ? 6 : 3);
   int Cc = 4;
   while (true) {
     const int next = Cc + 4;
@@ -322,6 +373,8 @@ hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st) {
     case 1: return lean_launch2<2, 4, 1, 4>(p, B, xfk, epi, st);
     case 2: return lean_launch2<4, 4, 1, 4>(p, B, xfk, epi, st);
     case 3: return lean_launch2<1, 1, 1, 4>(p, B, xfk, epi, st);
+    case 5: return lean_launch2<3, 4, 1, 4>(p, B, xfk, epi, st);
+    case 6: return lean_launch2<1, 2, 2, 2>(p, B, xfk, epi, st);
     default: return lean_launch2<1, 4, 4, 1>(p, B, xfk, epi, st);
   }
 }
