@@ -30,6 +30,16 @@ struct LeanP {
   float slope, in_scale, out_scale, add_scale, m_slope;
 };
 hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st);
+struct WgLeanP {
+  Opnd a; Opnd x;
+  int R, Cin, N, pad, K, reflect;
+  int lo, span, i0;
+  int ntiles;
+  float* slab; long slab_stride;
+  int vec;
+};
+bool wgrad_lean_supported(int J, int D);
+hipError_t launch_conv_wgrad_lean(WgLeanP p, int B, int J, int D, hipStream_t st);
 }  // namespace tdvc
 
 using namespace tdvc;
@@ -249,8 +259,14 @@ static bool wgrad_use_mfma(const WgradP& p) {
   return true;
 }
 
+static bool wgrad_lean_ok(const tdvc_conv_desc* d) {
+  return !g_force_generic && d->kind == TDVC_CONV && d->stride == 1 && d->groups == 1 && d->Tin == d->Tout && d->Tout > 128 &&
+         d->Cin >= 4 && wgrad_lean_supported(d->K, d->dilation);
+}
+
 extern "C" size_t tdvc_conv_wgrad_workspace(const tdvc_conv_desc* d) {
   if (check_desc(d)) return 0;
+  if (wgrad_lean_ok(d)) return (size_t)d->B * (size_t)((d->Tout + 255) / 256) * (size_t)d->Cout * d->Cin * d->K * sizeof(float);
   WgradP p = {};
   fill_wgrad(d, nullptr, p);
   if (!wgrad_use_mfma(p)) return 0;
@@ -268,7 +284,26 @@ extern "C" int tdvc_conv_wgrad(const tdvc_conv_desc* d, const tdvc_conv_wgrad_ar
   fill_wgrad(d, a, p);
   const long wsize = (long)d->groups * p.w_sg;
   hipError_t e = hipSuccess;
-  if (a->dw) {
+  bool done = false;
+  if (a->dw && wgrad_lean_ok(d)) {
+    WgLeanP q = {};
+    q.a = p.a; q.x = p.x; q.R = d->Cout; q.Cin = d->Cin; q.N = d->Tout; q.pad = d->pad; q.K = d->K; q.reflect = d->reflect;
+    const int nslab = d->B * ((d->Tout + 255) / 256);
+    const size_t need = (size_t)nslab * (size_t)wsize * sizeof(float);
+    if (!a->workspace || a->workspace_bytes < need) return tdvc_fail(TDVC_EWORKSPACE, "conv_wgrad: workspace too small");
+    q.slab = (float*)a->workspace; q.slab_stride = wsize;
+    auto okp = [](const Opnd& o) { return al16(o.p) && (o.bs & 3) == 0 && (o.T & 3) == 0 && (!o.xf.aux || (al16(o.xf.aux) && (o.xf.aux_bs & 3) == 0)); };
+    q.vec = (okp(q.a) && okp(q.x)) ? 1 : 0;
+    e = launch_conv_wgrad_lean(q, d->B, d->K, d->dilation, st);
+    if (e == hipSuccess) {
+      const int rowlen = d->Cin * d->K;
+      if (d->w_cin > 0) e = launch_slab_reduce(q.slab, nslab, wsize, wsize, a->dw + (long)d->w_cin_off * d->K, rowlen, (long)d->w_cin * d->K, st);
+      else e = launch_slab_reduce(q.slab, nslab, wsize, wsize, a->dw, rowlen, rowlen, st);
+      if (e != hipSuccess) return tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));
+      done = true;
+    } else if (e != hipErrorNotSupported) return tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));
+  }
+  if (a->dw && !done) {
     if (wgrad_use_mfma(p)) {
       int bpb;
       const int nslab = wgrad_geometry(p, d->B, &bpb);

@@ -1,0 +1,184 @@
+// Lean weight-gradient kernel for stride-1, groups == 1 convolutions with long sequences (N > 128):
+//   dW[co][ci][j] = sum_{b,t} dy'[co][t] * x'[ci][t + j*D - pad]
+// Per block: a (16*M_REP) x (16*C_REP) tile of (co, ci) for all J taps over one 256-step time chunk of one
+// sample; the 4 waves split the chunk (K-split) and are summed through LDS; partial tiles go to a slab that
+// slab_reduce_kernel folds into dW (deterministic, no atomics on the weights).
+// J (taps) and D (dilation) are template parameters and the LDS strides are constants, so every fragment
+// address in the MFMA loop is base + immediate: one vector add per step. Fragments of step s+1 are fetched
+// before the MFMAs of step s issue.
+#include "conv_common.h"
+
+namespace tdvc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+struct WgLeanP {
+  Opnd a;            // dy-like rows [B][R][N]
+  Opnd x;            // x-like rows  [B][Cin][T]
+  int R, Cin, N, pad, K, reflect;
+  int lo, span, i0;
+  int ntiles;
+  float* slab; long slab_stride;
+  int vec;
+};
+
+constexpr int WG_NTC = 256;
+constexpr int WG_AS = 258;     // 2 (mod 32)
+constexpr int WG_XS = 322;     // 2 (mod 32), >= 256 + (11-1)*5 + alignment slack
+
+template <int M_REP, int C_REP, int J, int D>
+__global__ __launch_bounds__(256, (M_REP * C_REP * J >= 24 ? 2 : 3)) void conv_wgrad_lean_kernel(const WgLeanP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int MT = 16 * M_REP, CT = 16 * C_REP;
+  constexpr int E = M_REP * C_REP * J * 4;
+  float* as = smem;                     // [MT][WG_AS]
+  float* xs = smem + MT * WG_AS;        // [CT][WG_XS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ln = lane & 15, kq = lane >> 4;
+  const int ctiles = (p.Cin + CT - 1) / CT;
+  const int ct = blockIdx.y % ctiles, mt = blockIdx.y / ctiles;
+  const int b = blockIdx.x / p.ntiles, tile = blockIdx.x % p.ntiles;
+  const int nc0 = tile * WG_NTC, r0 = mt * MT, c0 = ct * CT;
+
+  f32x4 acc[M_REP][C_REP][J];
+#pragma unroll
+  for (int m = 0; m < M_REP; ++m)
+#pragma unroll
+    for (int c = 0; c < C_REP; ++c)
+#pragma unroll
+      for (int j = 0; j < J; ++j) acc[m][c][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- stage both operand tiles (vector path for interior chunks, padding logic at the sequence ends)
+  const bool a_fast = p.vec && nc0 + WG_NTC <= p.N;
+  const bool x_fast = p.vec && nc0 + p.lo >= 0 && nc0 + p.lo + p.span <= p.x.T;
+  if (a_fast) stage_rows_batched<8>(p.a, as, WG_AS, b, r0, min(MT, p.R - r0), MT, nc0, WG_NTC, p.R, tid);
+  else {
+    for (int m = wave; m < MT; m += 4) {
+      const int row = r0 + m;
+      float* dst = as + m * WG_AS;
+      for (int i = lane; i < WG_NTC; i += 64) {
+        const int n = nc0 + i;
+        dst[i] = (row < p.R && n < p.N) ? fetch_opnd(p.a, b, row, n, 0, p.R) : 0.f;
+      }
+    }
+  }
+  if (x_fast) stage_rows_batched<8>(p.x, xs, WG_XS, b, c0, min(CT, p.Cin - c0), CT, nc0 + p.lo, p.span, p.Cin, tid);
+  else {
+    for (int r = wave; r < CT; r += 4) {
+      const int c = c0 + r;
+      float* dst = xs + r * WG_XS;
+      for (int i = lane; i < p.span; i += 64) dst[i] = (c < p.Cin) ? fetch_opnd(p.x, b, c, nc0 + p.lo + i, p.reflect, p.Cin) : 0.f;
+    }
+  }
+  __syncthreads();
+
+  // ---- MFMA: D[co][ci] += dy'[co][t] * x'[t + j*D][ci]; A = dy (row co = ln, k = kq), B = x (k = kq, col ci = ln)
+  constexpr int PER_WAVE = WG_NTC / 4;
+  const float* a_lane = as + ln * WG_AS + kq + wave * PER_WAVE;
+  const float* x_lane = xs + ln * WG_XS + kq + p.i0 + wave * PER_WAVE;
+  float av[2][M_REP], bv[2][C_REP][J];
+  auto load_frag = [&](int buf, int nn) {
+#pragma unroll
+    for (int m = 0; m < M_REP; ++m) av[buf][m] = a_lane[nn + m * 16 * WG_AS];
+#pragma unroll
+    for (int c = 0; c < C_REP; ++c)
+#pragma unroll
+      for (int j = 0; j < J; ++j) bv[buf][c][j] = x_lane[nn + c * 16 * WG_XS + j * D];
+  };
+  auto mma = [&](int buf) {
+#pragma unroll
+    for (int m = 0; m < M_REP; ++m)
+#pragma unroll
+      for (int c = 0; c < C_REP; ++c)
+#pragma unroll
+        for (int j = 0; j < J; ++j)
+          acc[m][c][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][m], bv[buf][c][j], acc[m][c][j], 0, 0, 0);
+  };
+  load_frag(0, 0);
+#pragma unroll 1
+  for (int nn = 0; nn < PER_WAVE; nn += 8) {
+    load_frag(1, nn + 4);
+    mma(0);
+    if (nn + 8 < PER_WAVE) load_frag(0, nn + 8);
+    mma(1);
+  }
+
+  // ---- cross-wave sum through LDS, then the block's partial tile goes to its slab
+  float* red = smem;
+  for (int w = 0; w < 4; ++w) {
+    __syncthreads();
+    if (wave == w) {
+#pragma unroll
+      for (int m = 0; m < M_REP; ++m)
+#pragma unroll
+        for (int c = 0; c < C_REP; ++c)
+#pragma unroll
+          for (int j = 0; j < J; ++j)
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int e = ((m * C_REP + c) * J + j) * 4 + r;
+              if (w == 0) red[e * 64 + lane] = acc[m][c][j][r];
+              else red[e * 64 + lane] += acc[m][c][j][r];
+            }
+    }
+  }
+  __syncthreads();
+  float* slab = p.slab + (long)blockIdx.x * p.slab_stride;
+  const long rowlen = (long)p.Cin * p.K;
+  for (int idx = tid; idx < E * 64; idx += 256) {
+    const int e = idx >> 6, l = idx & 63;
+    const int r = e & 3, mcj = e >> 2;
+    const int j = mcj % J, mc = mcj / J;
+    const int c = mc % C_REP, m = mc / C_REP;
+    const int row = r0 + m * 16 + (l >> 4) * 4 + r;
+    const int ci = c0 + c * 16 + (l & 15);
+    if (row < p.R && ci < p.Cin) slab[row * rowlen + (long)ci * p.K + j] = red[idx];
+  }
+}
+
+template <int M_REP, int C_REP, int J, int D>
+static hipError_t wg_launch(const WgLeanP& p, int B, hipStream_t st) {
+  constexpr int MT = 16 * M_REP, CT = 16 * C_REP;
+  auto k = conv_wgrad_lean_kernel<M_REP, C_REP, J, D>;
+  static bool once = false;
+  if (!once) { hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  dim3 grid(B * p.ntiles, ((p.R + MT - 1) / MT) * ((p.Cin + CT - 1) / CT), 1);
+  size_t lds = (size_t)(MT * WG_AS + CT * WG_XS) * sizeof(float);
+  const size_t red = (size_t)M_REP * C_REP * J * 4 * 64 * sizeof(float);
+  if (red > lds) lds = red;
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
+  return hipGetLastError();
+}
+
+template <int J, int D>
+static hipError_t wg_launch_jd(const WgLeanP& p, int B, hipStream_t st) {
+  if (p.R <= 16 || p.Cin <= 16) return wg_launch<1, 1, J, D>(p, B, st);
+  if (J <= 3) return wg_launch<2, 2, J, D>(p, B, st);
+  return wg_launch<2, 1, J, D>(p, B, st);
+}
+
+bool wgrad_lean_supported(int J, int D) {
+  if (J == 1) return D == 1;
+  if (J == 5) return D == 1;
+  return (J == 3 || J == 7 || J == 11) && (D == 1 || D == 3 || D == 5);
+}
+
+// number of slabs = B * ntiles; slab element layout = module weight layout [R][Cin][K]
+hipError_t launch_conv_wgrad_lean(WgLeanP p, int B, int J, int D, hipStream_t st) {
+  const int first = -p.pad;
+  p.lo = -(((-first) + 3) / 4 * 4);
+  p.i0 = first - p.lo;
+  p.span = ((WG_NTC + (J - 1) * D - p.pad - p.lo) + 3) / 4 * 4;
+  if (p.span > WG_XS - 2) return hipErrorNotSupported;
+  p.ntiles = (p.N + WG_NTC - 1) / WG_NTC;
+#define WG_CASE(JJ, DD) if (J == JJ && D == DD) return wg_launch_jd<JJ, DD>(p, B, st);
+  WG_CASE(1, 1) WG_CASE(5, 1)
+  WG_CASE(3, 1) WG_CASE(3, 3) WG_CASE(3, 5)
+  WG_CASE(7, 1) WG_CASE(7, 3) WG_CASE(7, 5)
+  WG_CASE(11, 1) WG_CASE(11, 3) WG_CASE(11, 5)
+#undef WG_CASE
+  return hipErrorNotSupported;
+}
+
+}  // namespace tdvc
