@@ -37,6 +37,7 @@ struct WgLeanP {
   int ntiles;
   float* slab; long slab_stride;
   int vec;
+  float* dbias;
 };
 bool wgrad_lean_supported(int J, int D);
 hipError_t launch_conv_wgrad_lean(WgLeanP p, int B, int J, int D, hipStream_t st);
@@ -284,7 +285,7 @@ extern "C" int tdvc_conv_wgrad(const tdvc_conv_desc* d, const tdvc_conv_wgrad_ar
   fill_wgrad(d, a, p);
   const long wsize = (long)d->groups * p.w_sg;
   hipError_t e = hipSuccess;
-  bool done = false;
+  bool done = false, bias_done = false;
   if (a->dw && wgrad_lean_ok(d)) {
     WgLeanP q = {};
     q.a = p.a; q.x = p.x; q.R = d->Cout; q.Cin = d->Cin; q.N = d->Tout; q.pad = d->pad; q.K = d->K; q.reflect = d->reflect;
@@ -294,13 +295,14 @@ extern "C" int tdvc_conv_wgrad(const tdvc_conv_desc* d, const tdvc_conv_wgrad_ar
     q.slab = (float*)a->workspace; q.slab_stride = wsize;
     auto okp = [](const Opnd& o) { return al16(o.p) && (o.bs & 3) == 0 && (o.T & 3) == 0 && (!o.xf.aux || (al16(o.xf.aux) && (o.xf.aux_bs & 3) == 0)); };
     q.vec = (okp(q.a) && okp(q.x)) ? 1 : 0;
+    q.dbias = a->dbias;
     e = launch_conv_wgrad_lean(q, d->B, d->K, d->dilation, st);
     if (e == hipSuccess) {
       const int rowlen = d->Cin * d->K;
       if (d->w_cin > 0) e = launch_slab_reduce(q.slab, nslab, wsize, wsize, a->dw + (long)d->w_cin_off * d->K, rowlen, (long)d->w_cin * d->K, st);
       else e = launch_slab_reduce(q.slab, nslab, wsize, wsize, a->dw, rowlen, rowlen, st);
       if (e != hipSuccess) return tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));
-      done = true;
+      done = true; bias_done = true;
     } else if (e != hipErrorNotSupported) return tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));
   }
   if (a->dw && !done) {
@@ -324,7 +326,7 @@ extern "C" int tdvc_conv_wgrad(const tdvc_conv_desc* d, const tdvc_conv_wgrad_ar
     }
     if (e != hipSuccess) return tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));
   }
-  if (a->dbias) {
+  if (a->dbias && !bias_done) {
     Opnd dy; dy.p = a->dy; dy.bs = a->dy_bs; dy.T = d->Tout; dy.Cg = d->Cout / d->groups; dy.xf = to_xf(a->dy_xf);
     e = launch_bias_grad(dy, d->Tout, d->Cout, d->B, a->dbias, st);
     if (e != hipSuccess) return tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));

@@ -20,6 +20,7 @@ struct WgLeanP {
   int ntiles;
   float* slab; long slab_stride;
   int vec;
+  float* dbias;      // optional: bias gradient accumulated from the staged dy' tile (row sums), atomics on R floats
 };
 
 constexpr int WG_NTC = 256;
@@ -72,6 +73,15 @@ __global__ __launch_bounds__(256, (M_REP * C_REP * J >= 24 ? 2 : 3)) void conv_w
     }
   }
   __syncthreads();
+
+  if (p.dbias && ct == 0) {   // dbias[co] += sum_t dy'[co][t]: 16 lanes per row, shuffle-reduced, one atomic per row
+    for (int rr = tid >> 4; rr < MT; rr += 16) {
+      float sacc = 0.f;
+      for (int i = tid & 15; i < WG_NTC; i += 16) sacc += as[rr * WG_AS + i];
+      sacc += __shfl_xor(sacc, 1); sacc += __shfl_xor(sacc, 2); sacc += __shfl_xor(sacc, 4); sacc += __shfl_xor(sacc, 8);
+      if ((tid & 15) == 0 && r0 + rr < p.R) atomicAdd(&p.dbias[r0 + rr], sacc);
+    }
+  }
 
   // ---- MFMA: D[co][ci] += dy'[co][t] * x'[t + j*D][ci]; A = dy (row co = ln, k = kq), B = x (k = kq, col ci = ln)
   constexpr int PER_WAVE = WG_NTC / 4;

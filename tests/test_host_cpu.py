@@ -1,0 +1,100 @@
+"""CPU: host-side logic of the product package — C-ABI symbols, state_dict layout, configs, synthetic inputs,
+and that the product path refuses to run without a GPU (no CPU fallback)."""
+import json
+import os
+import re
+
+import pytest
+import torch
+
+from common import D_ARGS, G_ARGS, GOLDEN, ROOT, pkg, shapes
+
+
+def test_library_exports_every_declared_symbol():
+    L = pkg()._lib
+    hdr = open(os.path.join(ROOT, 'include', 'tdvc.h')).read()
+    declared = set(re.findall(r'\b(tdvc_[a-z0-9_]+)\s*\(', hdr))
+    declared -= {'tdvc_status'}
+    lib = L.lib()                      # dlopen; raises if the .so is missing
+    for name in sorted(declared):
+        assert hasattr(lib, name), f'{name} declared in include/tdvc.h but not exported by libtdvc_hip.so'
+    assert declared <= set(L.SIGNATURES), declared - set(L.SIGNATURES)
+    assert lib.tdvc_version() >= 100
+    # argument validation happens on the host, before any launch
+    d = L.ConvDesc(L.CONV, 2, 16, 16, 100, 99, 3, 1, 1, 1, 1, 0, 0, 0)
+    assert lib.tdvc_conv_wgrad_workspace(d) == 0            # Tout inconsistent with the conv arithmetic
+    import ctypes as C
+    a = L.ConvFwdArgs()
+    assert lib.tdvc_conv_fwd(C.byref(d), C.byref(a), None) == -1
+    assert b'Tout' in lib.tdvc_last_error()
+
+
+def test_state_dict_matches_reference_layout():
+    M = pkg().modules
+    G = M.Generator(**{**G_ARGS, 'decoder_channels': list(G_ARGS['decoder_channels'])})
+    D = M.CollaborativeMultibandDiscriminator(**D_ARGS)
+    assert {k: list(v.shape) for k, v in G.state_dict().items()} == shapes('G')
+    assert {k: list(v.shape) for k, v in D.state_dict().items()} == shapes('D')
+    assert sum(p.numel() for p in G.parameters()) == 14619806 and sum(p.numel() for p in D.parameters()) == 17062368
+    cin = M.ConditionalInstanceNorm(32, 128)
+    assert {k: list(v.shape) for k, v in cin.state_dict().items()} == shapes('CIN')
+    C = M.LatentClassifier(16, 128)
+    assert {k: list(v.shape) for k, v in C.state_dict().items()} == shapes('C')
+
+
+def test_unsupported_configurations_raise():
+    M = pkg().modules
+    with pytest.raises(NotImplementedError):
+        M.Generator(**{**G_ARGS, 'encoder_model': 'wavlm'})
+    with pytest.raises(NotImplementedError):
+        M.Generator(**{**G_ARGS, 'norm_layer': ('instance_norm',) * 3})
+
+
+def test_no_cpu_fallback():
+    M = pkg().modules
+    D = M.CollaborativeMultibandDiscriminator(**D_ARGS)
+    with pytest.raises(RuntimeError):          # TdvcError: modules run on an MI355X device only
+        D(torch.zeros(1, 1, 8960), torch.zeros(1, dtype=torch.int64))
+
+
+def test_configs_and_step_config():
+    P = pkg()
+    for name, no_conv, idt in (('conv_enc-stage1', False, 5.0), ('conv_enc-stage2_1', True, 20.0)):
+        hp = P.hparams.HParam(os.path.join(ROOT, 'config', f'{name}.yaml'))
+        cfg = P.train_step.StepConfig.from_hparams(hp.train)
+        assert cfg.no_conv is no_conv and cfg.lambda_idt == idt and cfg.lambda_feat == 2 and cfg.lambda_spec == 5
+        assert cfg.betas == (0.8, 0.99) and cfg.weight_decay == 1e-2 and cfg.eps == 1e-8
+        assert hp.model.generator.decoder_ratios == [10, 8, 2, 2] and hp.model.discriminator.num_disc == 3
+
+
+def test_synthetic_batch_is_deterministic_and_shaped():
+    S = pkg().synth
+    a, b = S.make_batch(3, 8960, seed=5), S.make_batch(3, 8960, seed=5)
+    for k in a:
+        assert torch.equal(a[k], b[k]), k
+    assert a['signal_real'].shape == (3, 1, 8960) and a['c_f0_conv'].shape == (3, 1, 8960)
+    assert a['c_tgt'].shape == (3, 16) and torch.equal(a['c_tgt'].argmax(1), a['label_tgt'])
+    assert torch.equal(a['label_tgt'], a['label_src'][a['perm']])
+    rms = a['signal_real'].pow(2).mean(-1).sqrt()
+    assert float(rms.max()) <= 10 ** (-30 / 20) * 1.01 and float(rms.min()) >= 10 ** (-30 / 20) * 0.29
+    with pytest.raises(AssertionError):
+        S.make_batch(1, 3200)                                  # reflect padding needs T >= 8320
+    sd = S.fill_state_dict({'a.weight_v': [4, 3, 5], 'a.weight_g': [4, 1, 1], 'a.bias': [4]})
+    assert sd['a.weight_g'].shape == (4, 1, 1) and float(sd['a.weight_g'].min()) > 0
+
+
+def test_mel_filterbank_matches_oracle():
+    """Product-side mel filterbank / DFT basis (numpy float64) against the oracle's torch restatement."""
+    from oracle import losses as OL
+    LS = pkg().losses
+    fb = torch.from_numpy(LS._mel_filterbank(1025, 80, 16000)).float()
+    assert float((fb - OL.mel_filterbank(1025, 80, 16000)).abs().max()) < 1e-6
+    m = LS.MelSpec(16000, 512, 80)
+    # the DFT basis reproduces torch.stft on a centred frame
+    x = torch.randn(1, 1, 2048)
+    xp = torch.nn.functional.pad(x, (256, 256), mode='reflect')
+    spec = torch.nn.functional.conv1d(xp, m.basis, stride=128)          # [1, 2*Fp, N]
+    ref = torch.stft(x.reshape(1, -1), 512, hop_length=128, window=torch.hann_window(512), center=True,
+                     pad_mode='reflect', return_complex=True)
+    Fp = m.basis.shape[0] // 2
+    assert float((spec[0, :257] - ref[0].real).abs().max()) < 2e-3 and float((spec[0, Fp:Fp + 257] - ref[0].imag).abs().max()) < 2e-3
