@@ -11,7 +11,7 @@ template <int MODE> hipError_t launch_conv_wgrad(WgradP, int, int, hipStream_t);
 template <int MODE> hipError_t launch_conv_wgrad_scalar(WgradP, int, long, float*, hipStream_t);
 int wgrad_geometry(WgradP& p, int B, int* bpb_out);
 bool wgrad_mfma_supported(int J);
-hipError_t launch_slab_reduce(const float*, int, long, long, float*, int, long, hipStream_t);
+hipError_t launch_slab_reduce(const float*, int, long, long, float*, int, long, hipStream_t, long n_w = -1, float* dbias = nullptr);
 hipError_t launch_bias_grad(const Opnd&, int, int, int, float*, hipStream_t);
 }  // namespace tdvc
 
@@ -35,9 +35,10 @@ struct WgLeanP {
   int R, Cin, N, pad, K, reflect;
   int lo, span, i0;
   int ntiles;
+  int tpb, ngroups;
   float* slab; long slab_stride;
   int vec;
-  float* dbias;
+  long bias_off;
 };
 bool wgrad_lean_supported(int J, int D);
 hipError_t launch_conv_wgrad_lean(WgLeanP p, int B, int J, int D, hipStream_t st);
@@ -265,9 +266,25 @@ static bool wgrad_lean_ok(const tdvc_conv_desc* d) {
          d->Cin >= 4 && wgrad_lean_supported(d->K, d->dilation);
 }
 
+// chunks (256 time steps) per block: long sequences with many (row, channel) tiles loop over several chunks inside
+// one block so that the grid stays ~4 blocks per CU and the number of partial slabs shrinks with it
+static int wgrad_lean_tpb(const tdvc_conv_desc* d) {
+  const int ntiles = (d->Tout + 255) / 256;
+  const int mt = (d->Cout <= 16 || d->Cin <= 16) ? 16 : 32, ctw = (d->Cout <= 16 || d->Cin <= 16) ? 16 : (d->K <= 3 ? 32 : 16);
+  const long tiles = (long)((d->Cout + mt - 1) / mt) * ((d->Cin + ctw - 1) / ctw);
+  const long blocks = (long)d->B * ntiles * tiles;
+  int tpb = (int)(blocks / 1024);
+  if (tpb < 1) tpb = 1;
+  if (tpb > ntiles) tpb = ntiles;
+  return tpb;
+}
+
 extern "C" size_t tdvc_conv_wgrad_workspace(const tdvc_conv_desc* d) {
   if (check_desc(d)) return 0;
-  if (wgrad_lean_ok(d)) return (size_t)d->B * (size_t)((d->Tout + 255) / 256) * (size_t)d->Cout * d->Cin * d->K * sizeof(float);
+  if (wgrad_lean_ok(d)) {
+    const int ntiles = (d->Tout + 255) / 256, tpb = wgrad_lean_tpb(d);
+    return (size_t)d->B * (size_t)((ntiles + tpb - 1) / tpb) * ((size_t)d->Cout * d->Cin * d->K + d->Cout) * sizeof(float);
+  }
   WgradP p = {};
   fill_wgrad(d, nullptr, p);
   if (!wgrad_use_mfma(p)) return 0;
@@ -289,18 +306,22 @@ extern "C" int tdvc_conv_wgrad(const tdvc_conv_desc* d, const tdvc_conv_wgrad_ar
   if (a->dw && wgrad_lean_ok(d)) {
     WgLeanP q = {};
     q.a = p.a; q.x = p.x; q.R = d->Cout; q.Cin = d->Cin; q.N = d->Tout; q.pad = d->pad; q.K = d->K; q.reflect = d->reflect;
-    const int nslab = d->B * ((d->Tout + 255) / 256);
-    const size_t need = (size_t)nslab * (size_t)wsize * sizeof(float);
+    q.tpb = wgrad_lean_tpb(d);
+    const int ntl = (d->Tout + 255) / 256;
+    const int nslab = d->B * ((ntl + q.tpb - 1) / q.tpb);
+    const long sstride = wsize + d->Cout;                       // weights + per-slab bias partials
+    const size_t need = (size_t)nslab * (size_t)sstride * sizeof(float);
     if (!a->workspace || a->workspace_bytes < need) return tdvc_fail(TDVC_EWORKSPACE, "conv_wgrad: workspace too small");
-    q.slab = (float*)a->workspace; q.slab_stride = wsize;
+    q.slab = (float*)a->workspace; q.slab_stride = sstride;
     auto okp = [](const Opnd& o) { return al16(o.p) && (o.bs & 3) == 0 && (o.T & 3) == 0 && (!o.xf.aux || (al16(o.xf.aux) && (o.xf.aux_bs & 3) == 0)); };
     q.vec = (okp(q.a) && okp(q.x)) ? 1 : 0;
-    q.dbias = a->dbias;
+    q.bias_off = a->dbias ? wsize : -1;
     e = launch_conv_wgrad_lean(q, d->B, d->K, d->dilation, st);
     if (e == hipSuccess) {
       const int rowlen = d->Cin * d->K;
-      if (d->w_cin > 0) e = launch_slab_reduce(q.slab, nslab, wsize, wsize, a->dw + (long)d->w_cin_off * d->K, rowlen, (long)d->w_cin * d->K, st);
-      else e = launch_slab_reduce(q.slab, nslab, wsize, wsize, a->dw, rowlen, rowlen, st);
+      const long nred = a->dbias ? sstride : wsize;
+      if (d->w_cin > 0) e = launch_slab_reduce(q.slab, nslab, sstride, nred, a->dw + (long)d->w_cin_off * d->K, rowlen, (long)d->w_cin * d->K, st, wsize, a->dbias);
+      else e = launch_slab_reduce(q.slab, nslab, sstride, nred, a->dw, rowlen, rowlen, st, wsize, a->dbias);
       if (e != hipSuccess) return tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));
       done = true; bias_done = true;
     } else if (e != hipErrorNotSupported) return tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));

@@ -430,14 +430,19 @@ __global__ __launch_bounds__(256) void conv_bias_grad_kernel(const Opnd a, int N
 // dw[map(i)] += sum_s slab[s][i]; grid.y splits the slabs so small weights still fill the chip.
 // map: compact row-major [rows][rowlen] -> dst row stride (channel-window weights), identity otherwise.
 __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, int nslab, long stride, long n, float* dw,
-                                                          int rowlen, long dst_row_stride, int per_y) {
+                                                          int rowlen, long dst_row_stride, int per_y, long n_w, float* dbias) {
   const int s0 = blockIdx.y * per_y, s1 = min(nslab, s0 + per_y);
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
     float s = 0.f;
     for (int k = s0; k < s1; ++k) s += slab[(long)k * stride + i];
-    long dst = i;
-    if (dst_row_stride != rowlen) { const long r = i / rowlen; dst = r * dst_row_stride + (i - r * rowlen); }
-    if (gridDim.y == 1) dw[dst] += s; else atomicAdd(&dw[dst], s);
+    float* dstp;
+    if (i >= n_w) dstp = dbias + (i - n_w);          // trailing bias partials
+    else {
+      long dst = i;
+      if (dst_row_stride != rowlen) { const long r = i / rowlen; dst = r * dst_row_stride + (i - r * rowlen); }
+      dstp = dw + dst;
+    }
+    if (gridDim.y == 1) *dstp += s; else atomicAdd(dstp, s);
   }
 }
 
@@ -624,13 +629,14 @@ template hipError_t launch_conv_wgrad_scalar<MODE_DIRECT>(WgradP, int, long, flo
 template hipError_t launch_conv_wgrad_scalar<MODE_DOWN>(WgradP, int, long, float*, hipStream_t);
 
 hipError_t launch_slab_reduce(const float* slab, int nslab, long stride, long n, float* dw, int rowlen, long dst_row_stride,
-                              hipStream_t st) {
+                              hipStream_t st, long n_w = -1, float* dbias = nullptr) {
+  if (n_w < 0) n_w = n;
   int gx = (int)((n + 255) / 256); if (gx > 2048) gx = 2048; if (gx < 1) gx = 1;
   int gy = 1;
   if (nslab > 8) { gy = 1024 / gx; if (gy > (nslab + 7) / 8) gy = (nslab + 7) / 8; if (gy < 1) gy = 1; }
   const int per_y = (nslab + gy - 1) / gy;
   gy = (nslab + per_y - 1) / per_y;
-  hipLaunchKernelGGL(slab_reduce_kernel, dim3(gx, gy), dim3(256), 0, st, slab, nslab, stride, n, dw, rowlen, dst_row_stride, per_y);
+  hipLaunchKernelGGL(slab_reduce_kernel, dim3(gx, gy), dim3(256), 0, st, slab, nslab, stride, n, dw, rowlen, dst_row_stride, per_y, n_w, dbias);
   return hipGetLastError();
 }
 

@@ -17,10 +17,11 @@ struct WgLeanP {
   Opnd x;            // x-like rows  [B][Cin][T]
   int R, Cin, N, pad, K, reflect;
   int lo, span, i0;
-  int ntiles;
+  int ntiles;        // 256-step chunks per sample
+  int tpb, ngroups;  // chunks per block, chunk groups per sample (slabs = B * ngroups)
   float* slab; long slab_stride;
   int vec;
-  float* dbias;      // optional: bias gradient accumulated from the staged dy' tile (row sums), atomics on R floats
+  long bias_off;     // >= 0: per-slab bias partial sums (row sums of the staged dy' tile) at slab[bias_off + row]
 };
 
 constexpr int WG_NTC = 256;
@@ -39,8 +40,8 @@ __global__ __launch_bounds__(256, (M_REP * C_REP * J >= 24 ? 2 : 3)) void conv_w
   const int ln = lane & 15, kq = lane >> 4;
   const int ctiles = (p.Cin + CT - 1) / CT;
   const int ct = blockIdx.y % ctiles, mt = blockIdx.y / ctiles;
-  const int b = blockIdx.x / p.ntiles, tile = blockIdx.x % p.ntiles;
-  const int nc0 = tile * WG_NTC, r0 = mt * MT, c0 = ct * CT;
+  const int b = blockIdx.x / p.ngroups, grp = blockIdx.x % p.ngroups;
+  const int r0 = mt * MT, c0 = ct * CT;
 
   f32x4 acc[M_REP][C_REP][J];
 #pragma unroll
@@ -50,6 +51,13 @@ __global__ __launch_bounds__(256, (M_REP * C_REP * J >= 24 ? 2 : 3)) void conv_w
 #pragma unroll
       for (int j = 0; j < J; ++j) acc[m][c][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  float bias_part[MT / 16];   // thread (tid>>4) owns rows (tid>>4) + 16*i
+#pragma unroll
+  for (int i = 0; i < MT / 16; ++i) bias_part[i] = 0.f;
+  const int tile_end = min(p.ntiles, (grp + 1) * p.tpb);
+  for (int tile = grp * p.tpb; tile < tile_end; ++tile) {
+  const int nc0 = tile * WG_NTC;
+  __syncthreads();      // previous chunk's fragments fully consumed
   // ---- stage both operand tiles (vector path for interior chunks, padding logic at the sequence ends)
   const bool a_fast = p.vec && nc0 + WG_NTC <= p.N;
   const bool x_fast = p.vec && nc0 + p.lo >= 0 && nc0 + p.lo + p.span <= p.x.T;
@@ -74,12 +82,12 @@ __global__ __launch_bounds__(256, (M_REP * C_REP * J >= 24 ? 2 : 3)) void conv_w
   }
   __syncthreads();
 
-  if (p.dbias && ct == 0) {   // dbias[co] += sum_t dy'[co][t]: 16 lanes per row, shuffle-reduced, one atomic per row
+  if (p.bias_off >= 0 && ct == 0) {   // bias partial: sum_t dy'[co][t], 16 lanes per row, shuffle-reduced, kept per thread
     for (int rr = tid >> 4; rr < MT; rr += 16) {
       float sacc = 0.f;
       for (int i = tid & 15; i < WG_NTC; i += 16) sacc += as[rr * WG_AS + i];
       sacc += __shfl_xor(sacc, 1); sacc += __shfl_xor(sacc, 2); sacc += __shfl_xor(sacc, 4); sacc += __shfl_xor(sacc, 8);
-      if ((tid & 15) == 0 && r0 + rr < p.R) atomicAdd(&p.dbias[r0 + rr], sacc);
+      if ((tid & 15) == 0) bias_part[rr >> 4] += sacc;
     }
   }
 
@@ -113,6 +121,7 @@ __global__ __launch_bounds__(256, (M_REP * C_REP * J >= 24 ? 2 : 3)) void conv_w
     if (nn + 8 < PER_WAVE) load_frag(0, nn + 8);
     mma(1);
   }
+  }   // chunk loop
 
   // ---- cross-wave sum through LDS, then the block's partial tile goes to its slab
   float* red = smem;
@@ -145,6 +154,13 @@ __global__ __launch_bounds__(256, (M_REP * C_REP * J >= 24 ? 2 : 3)) void conv_w
     const int ci = c0 + c * 16 + (l & 15);
     if (row < p.R && ci < p.Cin) slab[row * rowlen + (long)ci * p.K + j] = red[idx];
   }
+  if (p.bias_off >= 0 && ct == 0 && (tid & 15) == 0) {
+#pragma unroll
+    for (int i = 0; i < MT / 16; ++i) {
+      const int row = r0 + (tid >> 4) + 16 * i;
+      if (row < p.R) slab[p.bias_off + row] = bias_part[i];
+    }
+  }
 }
 
 template <int M_REP, int C_REP, int J, int D>
@@ -153,7 +169,7 @@ static hipError_t wg_launch(const WgLeanP& p, int B, hipStream_t st) {
   auto k = conv_wgrad_lean_kernel<M_REP, C_REP, J, D>;
   static bool once = false;
   if (!once) { hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
-  dim3 grid(B * p.ntiles, ((p.R + MT - 1) / MT) * ((p.Cin + CT - 1) / CT), 1);
+  dim3 grid(B * p.ngroups, ((p.R + MT - 1) / MT) * ((p.Cin + CT - 1) / CT), 1);
   size_t lds = (size_t)(MT * WG_AS + CT * WG_XS) * sizeof(float);
   const size_t red = (size_t)M_REP * C_REP * J * 4 * 64 * sizeof(float);
   if (red > lds) lds = red;
@@ -182,6 +198,8 @@ hipError_t launch_conv_wgrad_lean(WgLeanP p, int B, int J, int D, hipStream_t st
   p.span = ((WG_NTC + (J - 1) * D - p.pad - p.lo) + 3) / 4 * 4;
   if (p.span > WG_XS - 2) return hipErrorNotSupported;
   p.ntiles = (p.N + WG_NTC - 1) / WG_NTC;
+  if (p.tpb < 1) p.tpb = 1;
+  p.ngroups = (p.ntiles + p.tpb - 1) / p.tpb;
 #define WG_CASE(JJ, DD) if (J == JJ && D == DD) return wg_launch_jd<JJ, DD>(p, B, st);
   WG_CASE(1, 1) WG_CASE(5, 1)
   WG_CASE(3, 1) WG_CASE(3, 3) WG_CASE(3, 5)

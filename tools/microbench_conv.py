@@ -18,7 +18,7 @@ SHAPES = {  # name: (cin, cout, k, dil, T, reflect, pre)
     'c16k3': (16, 16, 3, 1, 16000, True, 1), 'c16k11d5': (16, 16, 11, 5, 16000, True, 1), 'c16k1': (16, 16, 1, 1, 16000, False, 1),
     'c32k7d3': (32, 32, 7, 3, 8000, True, 1), 'c64k11': (64, 64, 11, 1, 4000, True, 1), 'c128k7': (128, 128, 7, 1, 500, True, 1),
     'cond0': (136, 136, 3, 1, 16000, False, 0), 'cond2_c16': (136, 32, 3, 1, 16000, False, 1), 'cond2_c64': (136, 128, 3, 1, 4000, False, 1),
-    'cond0x': (8, 136, 3, 1, 16000, False, 0), 'd5': (1024, 1024, 5, 1, 63, False, 0),
+    'cond0x': (8, 136, 3, 1, 16000, False, 0), 'c16k1_al': (16, 16, 1, 1, 16128, False, 1), 'c16k3_al': (16, 16, 3, 1, 16128, True, 1), 'd5': (1024, 1024, 5, 1, 63, False, 0),
 }
 
 
