@@ -126,8 +126,12 @@ def main():
     ix = pkg.synth.contrastive_indices(B, T // 320, cfg.n_neg, 17 + rank).to(dev)
     iy = pkg.synth.contrastive_indices(B, T // 320, cfg.n_neg, 917 + rank).to(dev)
 
-    def step():
-        return ts.run(bt, ix, iy)
+    use_graph = (world == 1) and not args.no_graph
+    if use_graph:
+        step = ts.capture(bt, ix, iy, warmup=2)      # whole iteration as one hipGraph
+    else:
+        def step():
+            return ts.run(bt, ix, iy)
 
     for _ in range(args.warmup):
         log = step()
@@ -172,7 +176,7 @@ def main():
                    scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
                    config=dict(workload=f'config/{args.config}.yaml full D+G iteration, {B} x 1 s @16 kHz per GPU, NUM_SPK=16, '
                                         'F0 (CREPE) loss term excluded', global_batch=world * B, parallelism=f'dp{world}'),
-                   roofline=roof, final_G_loss=g_loss)
+                   roofline=roof, final_G_loss=g_loss, launch='hipGraph replay' if use_graph else 'eager')
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(pkg, hp.train)
             out['speedup_vs_cpu'] = value / out['cpu_baseline']['value']

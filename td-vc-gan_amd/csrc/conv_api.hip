@@ -266,24 +266,14 @@ static bool wgrad_lean_ok(const tdvc_conv_desc* d) {
          d->Cin >= 4 && wgrad_lean_supported(d->K, d->dilation);
 }
 
-// chunks (256 time steps) per block: long sequences with many (row, channel) tiles loop over several chunks inside
-// one block so that the grid stays ~4 blocks per CU and the number of partial slabs shrinks with it
-static int wgrad_lean_tpb(const tdvc_conv_desc* d) {
-  const int ntiles = (d->Tout + 255) / 256;
-  const int mt = (d->Cout <= 16 || d->Cin <= 16) ? 16 : 32, ctw = (d->Cout <= 16 || d->Cin <= 16) ? 16 : (d->K <= 3 ? 32 : 16);
-  const long tiles = (long)((d->Cout + mt - 1) / mt) * ((d->Cin + ctw - 1) / ctw);
-  const long blocks = (long)d->B * ntiles * tiles;
-  int tpb = (int)(blocks / 1024);
-  if (tpb < 1) tpb = 1;
-  if (tpb > ntiles) tpb = ntiles;
-  return tpb;
-}
+namespace tdvc { void wgrad_lean_plan(int R, int Cin, int N, int K, int B, int* ntiles, int* tpb, int* ngroups); }
 
 extern "C" size_t tdvc_conv_wgrad_workspace(const tdvc_conv_desc* d) {
   if (check_desc(d)) return 0;
   if (wgrad_lean_ok(d)) {
-    const int ntiles = (d->Tout + 255) / 256, tpb = wgrad_lean_tpb(d);
-    return (size_t)d->B * (size_t)((ntiles + tpb - 1) / tpb) * ((size_t)d->Cout * d->Cin * d->K + d->Cout) * sizeof(float);
+    int ntiles, tpb, ngroups;
+    wgrad_lean_plan(d->Cout, d->Cin, d->Tout, d->K, d->B, &ntiles, &tpb, &ngroups);
+    return (size_t)d->B * (size_t)ngroups * ((size_t)d->Cout * d->Cin * d->K + d->Cout) * sizeof(float);
   }
   WgradP p = {};
   fill_wgrad(d, nullptr, p);
@@ -306,9 +296,8 @@ extern "C" int tdvc_conv_wgrad(const tdvc_conv_desc* d, const tdvc_conv_wgrad_ar
   if (a->dw && wgrad_lean_ok(d)) {
     WgLeanP q = {};
     q.a = p.a; q.x = p.x; q.R = d->Cout; q.Cin = d->Cin; q.N = d->Tout; q.pad = d->pad; q.K = d->K; q.reflect = d->reflect;
-    q.tpb = wgrad_lean_tpb(d);
-    const int ntl = (d->Tout + 255) / 256;
-    const int nslab = d->B * ((ntl + q.tpb - 1) / q.tpb);
+    wgrad_lean_plan(d->Cout, d->Cin, d->Tout, d->K, d->B, &q.ntiles, &q.tpb, &q.ngroups);
+    const int nslab = d->B * q.ngroups;
     const long sstride = wsize + d->Cout;                       // weights + per-slab bias partials
     const size_t need = (size_t)nslab * (size_t)sstride * sizeof(float);
     if (!a->workspace || a->workspace_bytes < need) return tdvc_fail(TDVC_EWORKSPACE, "conv_wgrad: workspace too small");

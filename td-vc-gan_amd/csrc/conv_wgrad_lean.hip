@@ -163,6 +163,169 @@ __global__ __launch_bounds__(256, (M_REP * C_REP * J >= 24 ? 2 : 3)) void conv_w
   }
 }
 
+// ----------------------------------------------------------------------------------------------
+// Register-tile variant for wide layers (R >= 32 and Cin >= 32): the 4 waves form a 2x2 grid over a
+// (32*M_REP) x (32*C_REP) tile of (co, ci) and each keeps its sub-tile (all J taps) in registers while the
+// block walks `tpb` consecutive 64-step time chunks; the operand rows of chunk i+1 are prefetched into
+// registers while the MFMAs of chunk i run (same issue-early / commit-late split as the forward kernel).
+// No cross-wave reduction; one slab per (sample, chunk group).
+constexpr int WT_NTC = 64;
+constexpr int WT_AS = 66;      // 2 (mod 32)
+constexpr int WT_XS = 130;     // 2 (mod 32), >= 64 + 50 + alignment slack
+
+template <int M_REP, int C_REP, int J, int D>
+__global__ __launch_bounds__(256, 2) void conv_wgrad_tile_kernel(const WgLeanP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int MT = 32 * M_REP, CT = 32 * C_REP;
+  constexpr int AV = (MT * (WT_NTC / 4) + 255) / 256;       // float4 per thread: dy rows
+  constexpr int XVN = (CT * 32 + 255) / 256;                // float4 per thread: x rows (span <= 128)
+  float* as = smem;                     // [MT][WT_AS]
+  float* xs = smem + MT * WT_AS;        // [CT][WT_XS]
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ln = lane & 15, kq = lane >> 4;
+  const int wm = wave >> 1, wc = wave & 1;
+  const int ctiles = (p.Cin + CT - 1) / CT;
+  const int ct = blockIdx.y % ctiles, mt = blockIdx.y / ctiles;
+  const int b = blockIdx.x / p.ngroups, grp = blockIdx.x % p.ngroups;
+  const int r0 = mt * MT, c0 = ct * CT;
+
+  f32x4 acc[M_REP][C_REP][J];
+#pragma unroll
+  for (int m = 0; m < M_REP; ++m)
+#pragma unroll
+    for (int c = 0; c < C_REP; ++c)
+#pragma unroll
+      for (int j = 0; j < J; ++j) acc[m][c][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bias_part[MT / 16];
+#pragma unroll
+  for (int i = 0; i < MT / 16; ++i) bias_part[i] = 0.f;
+
+  const int tile0 = grp * p.tpb, tile_end = min(p.ntiles, tile0 + p.tpb);
+  const bool simple = p.vec && p.a.xf.kind <= XF_LRELU && p.x.xf.kind <= XF_LRELU;   // register prefetch across chunks
+  const float* abase = p.a.p + (long)b * p.a.bs + (long)r0 * p.a.T;
+  const float* xbase = p.x.p + (long)b * p.x.bs + (long)c0 * p.x.T;
+  const int avalid = min(MT, p.R - r0), xvalid = min(CT, p.Cin - c0);
+  RegTile<AV> ar;
+  RegTile<XVN> xr;
+  auto chunk_fast = [&](int tile) {
+    const int nc0 = tile * WT_NTC;
+    return nc0 + WT_NTC <= p.N && nc0 + p.lo >= 0 && nc0 + p.lo + p.span <= p.x.T;
+  };
+  auto issue = [&](int tile) {
+    const int nc0 = tile * WT_NTC;
+    tile_issue<AV>(ar, abase + nc0, p.a.T, avalid, MT, WT_NTC, WT_NTC, 0, tid);
+    tile_issue<XVN>(xr, xbase + nc0 + p.lo, p.x.T, xvalid, CT, p.span, p.span, 0, tid);
+  };
+  bool have = false;
+  if (tile0 < tile_end && simple && chunk_fast(tile0)) { issue(tile0); have = true; }
+
+  for (int tile = tile0; tile < tile_end; ++tile) {
+    const int nc0 = tile * WT_NTC;
+    __syncthreads();
+    if (have) {
+      tile_commit<AV>(ar, nullptr, nullptr, p.a.xf, as, WT_AS, avalid, MT, WT_NTC, 0, tid);
+      tile_commit<XVN>(xr, nullptr, nullptr, p.x.xf, xs, WT_XS, xvalid, CT, p.span, 0, tid);
+    } else {
+      if (p.vec && nc0 + WT_NTC <= p.N) stage_rows_batched<4>(p.a, as, WT_AS, b, r0, avalid, MT, nc0, WT_NTC, p.R, tid);
+      else {
+        for (int m = wave; m < MT; m += 4) {
+          float* dst = as + m * WT_AS;
+          for (int i = lane; i < WT_NTC; i += 64) {
+            const int n = nc0 + i;
+            dst[i] = (r0 + m < p.R && n < p.N) ? fetch_opnd(p.a, b, r0 + m, n, 0, p.R) : 0.f;
+          }
+        }
+      }
+      if (p.vec && nc0 + p.lo >= 0 && nc0 + p.lo + p.span <= p.x.T) stage_rows_batched<4>(p.x, xs, WT_XS, b, c0, xvalid, CT, nc0 + p.lo, p.span, p.Cin, tid);
+      else {
+        for (int r = wave; r < CT; r += 4) {
+          float* dst = xs + r * WT_XS;
+          for (int i = lane; i < p.span; i += 64) dst[i] = (c0 + r < p.Cin) ? fetch_opnd(p.x, b, c0 + r, nc0 + p.lo + i, p.reflect, p.Cin) : 0.f;
+        }
+      }
+    }
+    __syncthreads();
+    have = false;
+    if (tile + 1 < tile_end && simple && chunk_fast(tile + 1)) { issue(tile + 1); have = true; }
+
+    if (p.bias_off >= 0 && ct == 0) {
+      for (int rr = tid >> 4; rr < MT; rr += 16) {
+        float sacc = 0.f;
+        for (int i = tid & 15; i < WT_NTC; i += 16) sacc += as[rr * WT_AS + i];
+        sacc += __shfl_xor(sacc, 1); sacc += __shfl_xor(sacc, 2); sacc += __shfl_xor(sacc, 4); sacc += __shfl_xor(sacc, 8);
+        if ((tid & 15) == 0) bias_part[rr >> 4] += sacc;
+      }
+    }
+
+    const float* a_lane = as + (wm * 16 * M_REP + ln) * WT_AS + kq;
+    const float* x_lane = xs + (wc * 16 * C_REP + ln) * WT_XS + kq + p.i0;
+    float av[2][M_REP], bv[2][C_REP][J];
+    auto load_frag = [&](int buf, int nn) {
+#pragma unroll
+      for (int m = 0; m < M_REP; ++m) av[buf][m] = a_lane[nn + m * 16 * WT_AS];
+#pragma unroll
+      for (int c = 0; c < C_REP; ++c)
+#pragma unroll
+        for (int j = 0; j < J; ++j) bv[buf][c][j] = x_lane[nn + c * 16 * WT_XS + j * D];
+    };
+    auto mma = [&](int buf) {
+#pragma unroll
+      for (int m = 0; m < M_REP; ++m)
+#pragma unroll
+        for (int c = 0; c < C_REP; ++c)
+#pragma unroll
+          for (int j = 0; j < J; ++j)
+            acc[m][c][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][m], bv[buf][c][j], acc[m][c][j], 0, 0, 0);
+    };
+    load_frag(0, 0);
+#pragma unroll 1
+    for (int nn = 0; nn < WT_NTC; nn += 8) {
+      load_frag(1, nn + 4);
+      mma(0);
+      if (nn + 8 < WT_NTC) load_frag(0, nn + 8);
+      mma(1);
+    }
+  }
+
+  float* slab = p.slab + (long)blockIdx.x * p.slab_stride;
+  const long rowlen = (long)p.Cin * p.K;
+#pragma unroll
+  for (int m = 0; m < M_REP; ++m)
+#pragma unroll
+    for (int c = 0; c < C_REP; ++c) {
+      const int ci = c0 + (wc * C_REP + c) * 16 + ln;
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int row = r0 + (wm * M_REP + m) * 16 + kq * 4 + r;
+        if (row < p.R && ci < p.Cin) {
+          float* dst = slab + row * rowlen + (long)ci * p.K;
+#pragma unroll
+          for (int j = 0; j < J; ++j) dst[j] = acc[m][c][j][r];
+        }
+      }
+    }
+  if (p.bias_off >= 0 && ct == 0 && (tid & 15) == 0) {
+#pragma unroll
+    for (int i = 0; i < MT / 16; ++i) {
+      const int row = r0 + (tid >> 4) + 16 * i;
+      if (row < p.R) slab[p.bias_off + row] = bias_part[i];
+    }
+  }
+}
+
+template <int M_REP, int C_REP, int J, int D>
+static hipError_t wt_launch(const WgLeanP& p, int B, hipStream_t st) {
+  constexpr int MT = 32 * M_REP, CT = 32 * C_REP;
+  auto k = conv_wgrad_tile_kernel<M_REP, C_REP, J, D>;
+  static bool once = false;
+  if (!once) { hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  dim3 grid(B * p.ngroups, ((p.R + MT - 1) / MT) * ((p.Cin + CT - 1) / CT), 1);
+  const size_t lds = (size_t)(MT * WT_AS + CT * WT_XS) * sizeof(float);
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
+  return hipGetLastError();
+}
+
 template <int M_REP, int C_REP, int J, int D>
 static hipError_t wg_launch(const WgLeanP& p, int B, hipStream_t st) {
   constexpr int MT = 16 * M_REP, CT = 16 * C_REP;
@@ -177,11 +340,37 @@ static hipError_t wg_launch(const WgLeanP& p, int B, hipStream_t st) {
   return hipGetLastError();
 }
 
+void wgrad_lean_plan(int R, int Cin, int N, int K, int B, int* ntiles, int* tpb, int* ngroups);
+
 template <int J, int D>
-static hipError_t wg_launch_jd(const WgLeanP& p, int B, hipStream_t st) {
+static hipError_t wg_launch_jd(WgLeanP& p, int B, hipStream_t st) {
+  wgrad_lean_plan(p.R, p.Cin, p.N, p.K, B, &p.ntiles, &p.tpb, &p.ngroups);
   if (p.R <= 16 || p.Cin <= 16) return wg_launch<1, 1, J, D>(p, B, st);
-  if (J <= 3) return wg_launch<2, 2, J, D>(p, B, st);
-  return wg_launch<2, 1, J, D>(p, B, st);
+  // wide layers: 64-step chunks, register tile per wave
+  p.span = ((WT_NTC + (J - 1) * D - p.pad - p.lo) + 3) / 4 * 4;
+  if (p.R <= 32) {
+    if (J <= 3) return wt_launch<1, 2, J, D>(p, B, st);    // 32 x 64 block tile, 16 x 32 per wave
+    return wt_launch<1, 1, J, D>(p, B, st);                 // 32 x 32 block tile
+  }
+  if (J <= 3) return wt_launch<2, 2, J, D>(p, B, st);      // 64 x 64 block tile, 32 x 32 per wave
+  return wt_launch<2, 1, J, D>(p, B, st);                   // 64 x 32 block tile, 32 x 16 per wave
+}
+
+// Grid plan shared by the workspace query and the launch: chunk length, chunks per block, chunk groups per sample.
+void wgrad_lean_plan(int R, int Cin, int N, int K, int B, int* ntiles, int* tpb, int* ngroups) {
+  const bool narrow = (R <= 16 || Cin <= 16);
+  const int ntc = narrow ? WG_NTC : WT_NTC;
+  const int mt = narrow ? 16 : (R <= 32 ? 32 : 64), ctw = narrow ? 16 : (K <= 3 ? 64 : 32);
+  *ntiles = (N + ntc - 1) / ntc;
+  const long tiles = (long)((R + mt - 1) / mt) * ((Cin + ctw - 1) / ctw);
+  const long blocks = (long)B * (*ntiles) * tiles;
+  // narrow: ~4 blocks per CU (latency-bound, no intra-block pipeline); wide: ~2 per CU, the register-tile kernel
+  // prefetches across chunks, and fewer, longer blocks mean fewer partial slabs to write and fold
+  int t = (int)(blocks / (narrow ? 1024 : 512));
+  if (t < 1) t = 1;
+  if (t > *ntiles) t = *ntiles;
+  *tpb = t;
+  *ngroups = (*ntiles + t - 1) / t;
 }
 
 bool wgrad_lean_supported(int J, int D) {
@@ -197,9 +386,6 @@ hipError_t launch_conv_wgrad_lean(WgLeanP p, int B, int J, int D, hipStream_t st
   p.i0 = first - p.lo;
   p.span = ((WG_NTC + (J - 1) * D - p.pad - p.lo) + 3) / 4 * 4;
   if (p.span > WG_XS - 2) return hipErrorNotSupported;
-  p.ntiles = (p.N + WG_NTC - 1) / WG_NTC;
-  if (p.tpb < 1) p.tpb = 1;
-  p.ngroups = (p.ntiles + p.tpb - 1) / p.tpb;
 #define WG_CASE(JJ, DD) if (J == JJ && D == DD) return wg_launch_jd<JJ, DD>(p, B, st);
   WG_CASE(1, 1) WG_CASE(5, 1)
   WG_CASE(3, 1) WG_CASE(3, 3) WG_CASE(3, 5)

@@ -147,3 +147,29 @@ class TrainStep:
         self.d_step(batch, log)
         self.g_step(batch, log, idx_x, idx_y)
         return log
+
+    def capture(self, batch, idx_x, idx_y, warmup=2):
+        """Capture the whole iteration (≈3.5k kernel launches, both backward passes, both AdamW updates) into one
+        hipGraph and return `replay() -> log`. The batch tensors are static inputs: copy new data into them
+        between replays. Everything the step touches is graph-safe by construction: no host sync, no allocation
+        outside the torch caching allocator, wgrad workspace sized during the eager warm-up, AdamW step counter
+        on the device. Data-parallel runs stay eager (the RCCL all-reduce is not captured)."""
+        if self.grad_sync is not None:
+            raise RuntimeError('graph capture is single-GPU only; run data-parallel steps eagerly')
+        dev = self.device
+        side = torch.cuda.Stream(dev)
+        side.wait_stream(torch.cuda.current_stream(dev))
+        with torch.cuda.stream(side):
+            for _ in range(warmup):
+                self.run(batch, idx_x, idx_y)
+        torch.cuda.current_stream(dev).wait_stream(side)
+        torch.cuda.synchronize(dev)
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            log = self.run(batch, idx_x, idx_y)
+
+        def replay():
+            graph.replay()
+            return log
+        replay.graph = graph
+        return replay
