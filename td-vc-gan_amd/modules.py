@@ -362,6 +362,31 @@ class Generator(ArenaModule):
         return self.decoder(content, emb, c_var, out_subsample=out_subsample)
 
 
+def generator_forward_pair(G, x, x_other, conds, c_vars):
+    """Product-side fast path for one training iteration (not part of the reference surface):
+    the encoder runs ONCE on cat([x, x_other]) (real + corrupted signals) and the decoder runs ONCE on the
+    real-signal content replicated per conditioning in `conds` / `c_vars` (target-speaker pass and identity pass).
+    Exactly the arithmetic of separate G(x, c, c_var) calls — the reference recomputes the identical encoder
+    output for each conditioning (train.py:322,367) — with 2x the work per launch.
+    Returns ([(y, subs)] per conditioning, emb_x, emb_other)."""
+    G.begin_forward(x)
+    B = x.shape[0]
+    top, G.encoder._top = G.encoder._top, None
+    try:
+        both = G.encoder(torch.cat([x, x_other], dim=0) if x_other is not None else x)
+    finally:
+        G.encoder._top = top
+    emb_x = both[:B]
+    emb_other = both[B:] if x_other is not None else None
+    n = len(conds)
+    emb = G.embedding(torch.cat([c.contiguous().float() for c in conds], dim=0))
+    content = torch.cat([emb_x] * n, dim=0) if n > 1 else emb_x
+    y, subs = G.decoder(content, emb, torch.cat(list(c_vars), dim=0) if n > 1 else c_vars[0], out_subsample=True)
+    outs = [(y[i * B:(i + 1) * B], [s_[i * B:(i + 1) * B] for s_ in subs]) for i in range(n)]
+    G.content_embedding = emb_x
+    return outs, emb_x, emb_other
+
+
 # ------------------------------------------------------------------------------- discriminator
 class Discriminator(nn.Module):
     def __init__(self, num_classes, num_layers, num_channels_base, num_channel_mult=4, downsampling_factor=4,
@@ -399,15 +424,33 @@ class CollaborativeMultibandDiscriminator(ArenaModule):
         self.down = FixedFIR(kaiser_filter_odd(self.L, 0.5, 10), 1, 2, (self.L - 1) // 2)
 
     def forward(self, x, label_tgt, subscales=[]):
+        """Returns (outs, features) in the reference's order: disc0@T, disc1@T/2, disc2@T/4, then the sub-scale
+        passes disc2@sub[T/4], disc1@sub[T/2]. A discriminator that sees both a filtered and a sub-scale input of
+        the same length runs them as ONE pass with the batch doubled (exact: D has no cross-sample op) — the
+        short, latency-bound layers get twice the work per launch."""
         self.begin_forward(x)
         x = x.contiguous().float()
-        ret = []
+        n = len(self.discriminators)
+        B = x.shape[0]
+        xs = [x]
+        for _ in range(n - 1):
+            xs.append(self.down(xs[-1]))
+        subs = {}                       # discriminator index -> sub-scale input
+        for x_sub, i in zip(subscales, reversed(range(n))):
+            subs[i] = x_sub.contiguous().float()
+        main, extra = [None] * n, {}
         for i, disc in enumerate(self.discriminators):
-            ret.append(disc(x, label_tgt))
-            if i + 1 < len(self.discriminators):     # the reference filters once more and drops the result
-                x = self.down(x)
-        for x_sub, disc in zip(subscales, reversed(self.discriminators)):
-            ret.append(disc(x_sub.contiguous(), label_tgt))
+            if i in subs and subs[i].shape == xs[i].shape:
+                o, f = disc(torch.cat([xs[i], subs[i]], dim=0), torch.cat([label_tgt, label_tgt], dim=0))
+                main[i] = (o[:B], [m[:B] for m in f])
+                extra[i] = (o[B:], [m[B:] for m in f])
+            else:
+                main[i] = disc(xs[i], label_tgt)
+                if i in subs:
+                    extra[i] = disc(subs[i], label_tgt)
+        ret = list(main)
+        for _, i in zip(subscales, reversed(range(n))):
+            ret.append(extra[i])
         out, features = zip(*ret)
         return list(out), list(features)
 

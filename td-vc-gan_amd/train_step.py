@@ -63,24 +63,39 @@ class TrainStep:
         ga.materialize(); da.materialize()
 
     # -------------------------------------------------------------------------------------------
-    def _gen(self, batch, c, c_var):
-        y, subs = self.G(batch['signal_real'], c, c_var=c_var, out_subsample=True)
-        return y, subs, self.G.content_embedding
+    def _generate(self, batch):
+        """All generator work of the iteration in one batched pass (G's weights do not change between the D-step and
+        the G-step): encoder on [real; corrupted], decoder on [target-conditioned; identity-conditioned]."""
+        from .modules import generator_forward_pair
+        c = self.cfg
+        want_idt = c.lambda_idt > 0 and not c.no_conv
+        want_cor = c.lambda_cont_emb > 0 and bool(c.lambda_corrupted)
+        conds = [batch['c_tgt']] + ([batch['c_src']] if want_idt else [])
+        cvars = [batch['c_f0_conv']] + ([batch['c_f0_src']] if want_idt else [])
+        outs, emb_real, emb_cor = generator_forward_pair(self.G, batch['signal_real'], batch['signal_corrupted'] if want_cor else None,
+                                                         conds, cvars)
+        fake = outs[0]
+        idt = outs[1] if want_idt else (fake if c.lambda_idt > 0 else None)
+        return fake, idt, emb_real, emb_cor
 
     def d_step(self, batch, log):
-        G, D = self.G, self.D
+        D = self.D
         if self.reuse_fake:
-            fake, fake_subs, emb_real = self._gen(batch, batch['c_tgt'], batch['c_f0_conv'])
-            self._fake = (fake, fake_subs, emb_real)
+            self._gen_out = self._generate(batch)
+            (fake, fake_subs) = self._gen_out[0]
         else:
             with torch.no_grad():
-                fake, fake_subs, _ = self._gen(batch, batch['c_tgt'], batch['c_f0_conv'])
+                (fake, fake_subs) = self._generate(batch)[0]
         real = batch['signal_real']
+        B = real.shape[0]
         self._real_subs = D.get_subsamples(real)
-        out_real, _ = D(real, batch['label_src'], self._real_subs)
-        out_fake, _ = D(fake.detach(), batch['label_tgt'], [s.detach() for s in fake_subs])
-        l_real = LS.lsgan_loss(out_real, 1.0)
-        l_fake = LS.lsgan_loss(out_fake, 0.0)
+        # real and fake in ONE discriminator call (batch 2B): exact, D has no cross-sample op
+        x2 = torch.cat([real, fake.detach()], dim=0)
+        l2 = torch.cat([batch['label_src'], batch['label_tgt']], dim=0)
+        s2 = [torch.cat([r, f.detach()], dim=0) for r, f in zip(self._real_subs, fake_subs)]
+        outs, _ = D(x2, l2, s2)
+        l_real = LS.lsgan_loss([o[:B] for o in outs], 1.0)
+        l_fake = LS.lsgan_loss([o[B:] for o in outs], 0.0)
         d_loss = l_real + l_fake
         self.opt_d.zero_grad()
         d_loss.backward()
@@ -93,29 +108,41 @@ class TrainStep:
     def g_step(self, batch, log, idx_x=None, idx_y=None):
         G, D, c = self.G, self.D, self.cfg
         real = batch['signal_real']
+        B = real.shape[0]
         D.arena.wgrad_enabled = False                     # Q5
         try:
             if self.reuse_fake:
-                fake, fake_subs, emb_real = self._fake
-                self._fake = None
+                (fake, fake_subs), idt_pair, emb_real, emb_cor = self._gen_out
+                self._gen_out = None
             else:
-                fake, fake_subs, emb_real = self._gen(batch, batch['c_tgt'], batch['c_f0_conv'])
-            out_fake, _ = D(fake, batch['label_tgt'], fake_subs)
+                (fake, fake_subs), idt_pair, emb_real, emb_cor = self._generate(batch)
+            need_feat = c.lambda_idt > 0 and c.lambda_feat > 0
+            separate_idt = need_feat and idt_pair is not None and idt_pair[0] is not fake
+            if separate_idt:    # fake and identity signals through D in one call (batch 2B)
+                idt, idt_subs = idt_pair
+                outs, feats = D(torch.cat([fake, idt], dim=0), torch.cat([batch['label_tgt'], batch['label_src']], dim=0),
+                                [torch.cat([a, b_], dim=0) for a, b_ in zip(fake_subs, idt_subs)])
+                out_fake = [o[:B] for o in outs]
+                feats_idt = [[m[B:] for m in fl] for fl in feats]
+            else:
+                out_fake, feats_fake = D(fake, batch['label_tgt'], fake_subs)
+                idt, idt_subs = (fake, fake_subs) if idt_pair is not None else (None, None)
+                # no_conv: the identity signal IS the converted signal, but it is judged with label_src (train.py:374)
+                feats_idt = None
+                if need_feat and idt is not None:
+                    # no_conv: label_tgt IS label_src (train.py:217), so D(idt, label_src) == D(fake, label_tgt)
+                    if c.no_conv:
+                        feats_idt = feats_fake
+                    else:
+                        _, feats_idt = D(idt, batch['label_src'], idt_subs)
             adv = LS.lsgan_loss(out_fake, 1.0)
             total = adv
             log['G_loss_adv_fake'] = adv.detach()
-            feats_real = None
-            if (c.lambda_rec > 0 or c.lambda_idt > 0) and c.lambda_feat > 0:
-                with torch.no_grad():                      # Q6
-                    _, feats_real = D(real, batch['label_src'], self._real_subs)
-            if c.lambda_idt > 0:
-                if c.no_conv:
-                    idt, idt_subs = fake, fake_subs
-                else:
-                    idt, idt_subs, _ = self._gen(batch, batch['c_src'], batch['c_f0_src'])
+            if c.lambda_idt > 0 and idt is not None:
                 l_idt = None
-                if c.lambda_feat > 0:
-                    _, feats_idt = D(idt, batch['label_src'], idt_subs)
+                if need_feat:
+                    with torch.no_grad():                  # Q6
+                        _, feats_real = D(real, batch['label_src'], self._real_subs)
                     l_feat = LS.multiscale_feat_loss(feats_idt, feats_real, norm_p=1)
                     log['G_loss_idt_feat'] = l_feat.detach()
                     l_idt = c.lambda_feat * l_feat
@@ -126,8 +153,7 @@ class TrainStep:
                 if l_idt is not None:
                     log['G_loss_idt'] = l_idt.detach()
                     total = total + c.lambda_idt * l_idt
-            if c.lambda_cont_emb > 0 and c.lambda_corrupted:
-                emb_cor = G.encoder(batch['signal_corrupted'])
+            if emb_cor is not None:
                 l_con = LS.contrastive_loss(emb_real, emb_cor, num_negatives=c.n_neg, temp=0.1, idx_x=idx_x, idx_y=idx_y)
                 log['G_loss_cont_emb'] = l_con.detach()
                 total = total + c.lambda_cont_emb * l_con
