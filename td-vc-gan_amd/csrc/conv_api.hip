@@ -32,7 +32,7 @@ struct LeanP {
 hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st);
 struct WgLeanP {
   Opnd a; Opnd x;
-  int R, Cin, N, pad, K, reflect;
+  int R, Cin, N, pad, K, reflect, B;
   int lo, span, i0;
   int ntiles;
   int tpb, ngroups;
@@ -262,18 +262,17 @@ static bool wgrad_use_mfma(const WgradP& p) {
 }
 
 static bool wgrad_lean_ok(const tdvc_conv_desc* d) {
-  return !g_force_generic && d->kind == TDVC_CONV && d->stride == 1 && d->groups == 1 && d->Tin == d->Tout && d->Tout > 128 &&
-         d->Cin >= 4 && wgrad_lean_supported(d->K, d->dilation);
+  const bool wide = d->Cout >= 32 && d->Cin >= 32;     // register-tile kernel: walks (sample, tile) chunks, any length
+  return !g_force_generic && d->kind == TDVC_CONV && d->stride == 1 && d->groups == 1 && d->Tin == d->Tout &&
+         (d->Tout > 128 || wide) && d->Cin >= 4 && wgrad_lean_supported(d->K, d->dilation);
 }
 
-namespace tdvc { void wgrad_lean_plan(int R, int Cin, int N, int K, int B, int* ntiles, int* tpb, int* ngroups); }
+namespace tdvc { int wgrad_lean_nslab(int R, int Cin, int N, int K, int B); }
 
 extern "C" size_t tdvc_conv_wgrad_workspace(const tdvc_conv_desc* d) {
   if (check_desc(d)) return 0;
   if (wgrad_lean_ok(d)) {
-    int ntiles, tpb, ngroups;
-    wgrad_lean_plan(d->Cout, d->Cin, d->Tout, d->K, d->B, &ntiles, &tpb, &ngroups);
-    return (size_t)d->B * (size_t)ngroups * ((size_t)d->Cout * d->Cin * d->K + d->Cout) * sizeof(float);
+    return (size_t)wgrad_lean_nslab(d->Cout, d->Cin, d->Tout, d->K, d->B) * ((size_t)d->Cout * d->Cin * d->K + d->Cout) * sizeof(float);
   }
   WgradP p = {};
   fill_wgrad(d, nullptr, p);
@@ -296,8 +295,7 @@ extern "C" int tdvc_conv_wgrad(const tdvc_conv_desc* d, const tdvc_conv_wgrad_ar
   if (a->dw && wgrad_lean_ok(d)) {
     WgLeanP q = {};
     q.a = p.a; q.x = p.x; q.R = d->Cout; q.Cin = d->Cin; q.N = d->Tout; q.pad = d->pad; q.K = d->K; q.reflect = d->reflect;
-    wgrad_lean_plan(d->Cout, d->Cin, d->Tout, d->K, d->B, &q.ntiles, &q.tpb, &q.ngroups);
-    const int nslab = d->B * q.ngroups;
+    const int nslab = wgrad_lean_nslab(d->Cout, d->Cin, d->Tout, d->K, d->B);
     const long sstride = wsize + d->Cout;                       // weights + per-slab bias partials
     const size_t need = (size_t)nslab * (size_t)sstride * sizeof(float);
     if (!a->workspace || a->workspace_bytes < need) return tdvc_fail(TDVC_EWORKSPACE, "conv_wgrad: workspace too small");

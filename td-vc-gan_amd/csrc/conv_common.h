@@ -183,4 +183,44 @@ __device__ __forceinline__ void stage_rows_batched(const Opnd& o, float* dst, in
   }
 }
 
+
+// Scalar (dword) register tile with full padding logic: used for short / unaligned sequences (T = 50, 63, ...) and
+// for the chunks at the sequence ends, so that those too are prefetched one chunk ahead instead of being staged
+// element by element. Supports the prologues NONE / LRELU (aux unused) and MASK_LRELU (aux = activation output).
+template <int NS>
+struct RegS { float v[NS]; };
+
+template <int NS>
+__device__ __forceinline__ void tile_issue_s(RegS<NS>& t, const float* base, int T, int nvalid, int nrows, int span, int q0,
+                                             int reflect, int tid) {
+  const int total = nrows * span;
+  const float inv = 1.0f / (float)span;
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int e = tid + i * 256;
+    const int r = (int)(((float)e + 0.5f) * inv);
+    int q = q0 + (e - r * span);
+    if (reflect) { if (q < 0) q = -q; else if (q >= T) q = 2 * (T - 1) - q; }
+    t.v[i] = 0.f;
+    if (e < total && r < nvalid && q >= 0 && q < T) t.v[i] = base[(long)r * T + q];
+  }
+}
+
+template <int NS>
+__device__ __forceinline__ void tile_commit_s(const RegS<NS>& t, const RegS<NS>* a, const Xf& xf, float* dst, int XS, int nrows,
+                                              int span, int tid) {
+  const int total = nrows * span;
+  const float inv = 1.0f / (float)span;
+#pragma unroll
+  for (int i = 0; i < NS; ++i) {
+    const int e = tid + i * 256;
+    if (e >= total) continue;
+    const int r = (int)(((float)e + 0.5f) * inv);
+    float v = t.v[i];
+    if (xf.kind == XF_LRELU) v = fmaxf(v, v * xf.slope);
+    else if (xf.kind == XF_MASK_LRELU) v = a->v[i] > 0.f ? v : v * xf.slope;
+    dst[r * XS + (e - r * span)] = v * xf.scale;
+  }
+}
+
 }  // namespace tdvc

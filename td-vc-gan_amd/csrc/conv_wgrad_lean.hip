@@ -15,7 +15,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 struct WgLeanP {
   Opnd a;            // dy-like rows [B][R][N]
   Opnd x;            // x-like rows  [B][Cin][T]
-  int R, Cin, N, pad, K, reflect;
+  int R, Cin, N, pad, K, reflect, B;
   int lo, span, i0;
   int ntiles;        // 256-step chunks per sample
   int tpb, ngroups;  // chunks per block, chunk groups per sample (slabs = B * ngroups)
@@ -173,12 +173,17 @@ constexpr int WT_NTC = 64;
 constexpr int WT_AS = 66;      // 2 (mod 32)
 constexpr int WT_XS = 130;     // 2 (mod 32), >= 64 + 50 + alignment slack
 
-template <int M_REP, int C_REP, int J, int D>
+// SCAL = false: aligned float4 prefetch (long sequences; the chunks at the sequence ends fall back to element-wise
+// staging); SCAL = true: scalar prefetch with padding logic for every chunk (short / unaligned sequences, masked dy).
+template <int M_REP, int C_REP, int J, int D, bool SCAL>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_tile_kernel(const WgLeanP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int MT = 32 * M_REP, CT = 32 * C_REP;
   constexpr int AV = (MT * (WT_NTC / 4) + 255) / 256;       // float4 per thread: dy rows
   constexpr int XVN = (CT * 32 + 255) / 256;                // float4 per thread: x rows (span <= 128)
+  constexpr int AS_N = SCAL ? (MT * WT_NTC + 255) / 256 : 1;   // scalars per thread (unaligned / edge chunks)
+  constexpr int XS_N = SCAL ? (CT * 128 + 255) / 256 : 1;
+  constexpr int AVV = SCAL ? 1 : AV, XVV = SCAL ? 1 : XVN;
   float* as = smem;                     // [MT][WT_AS]
   float* xs = smem + MT * WT_AS;        // [CT][WT_XS]
 
@@ -187,7 +192,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile_kernel(const WgLeanP p
   const int wm = wave >> 1, wc = wave & 1;
   const int ctiles = (p.Cin + CT - 1) / CT;
   const int ct = blockIdx.y % ctiles, mt = blockIdx.y / ctiles;
-  const int b = blockIdx.x / p.ngroups, grp = blockIdx.x % p.ngroups;
   const int r0 = mt * MT, c0 = ct * CT;
 
   f32x4 acc[M_REP][C_REP][J];
@@ -201,53 +205,63 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile_kernel(const WgLeanP p
 #pragma unroll
   for (int i = 0; i < MT / 16; ++i) bias_part[i] = 0.f;
 
-  const int tile0 = grp * p.tpb, tile_end = min(p.ntiles, tile0 + p.tpb);
-  const bool simple = p.vec && p.a.xf.kind <= XF_LRELU && p.x.xf.kind <= XF_LRELU;   // register prefetch across chunks
-  const float* abase = p.a.p + (long)b * p.a.bs + (long)r0 * p.a.T;
-  const float* xbase = p.x.p + (long)b * p.x.bs + (long)c0 * p.x.T;
+  // chunks are (sample, 64-step tile) pairs: q -> (b = q / ntiles, tile = q % ntiles); a block owns tpb of them
+  const int nchunks = p.ntiles * p.B;
+  const int q_begin = blockIdx.x * p.tpb, q_end = min(nchunks, q_begin + p.tpb);
   const int avalid = min(MT, p.R - r0), xvalid = min(CT, p.Cin - c0);
-  RegTile<AV> ar;
-  RegTile<XVN> xr;
-  auto chunk_fast = [&](int tile) {
-    const int nc0 = tile * WT_NTC;
-    return nc0 + WT_NTC <= p.N && nc0 + p.lo >= 0 && nc0 + p.lo + p.span <= p.x.T;
+  const int akind = p.a.xf.kind, xkind = p.x.xf.kind;
+  // mode per chunk: 2 = aligned float4 prefetch, 1 = scalar prefetch with padding logic, 0 = element-wise fallback
+  const bool vec_kinds = akind <= XF_LRELU && xkind <= XF_LRELU;
+  const bool sc_kinds = (akind <= XF_LRELU || akind == XF_MASK_LRELU) && xkind <= XF_LRELU && p.span <= 128;
+  auto chunk_mode = [&](int q) {
+    const int tile = q % p.ntiles, nc0 = tile * WT_NTC;
+    if (!SCAL) return (p.vec && vec_kinds && nc0 + WT_NTC <= p.N && nc0 + p.lo >= 0 && nc0 + p.lo + p.span <= p.x.T) ? 2 : 0;
+    return sc_kinds ? 1 : 0;
   };
-  auto issue = [&](int tile) {
-    const int nc0 = tile * WT_NTC;
-    tile_issue<AV>(ar, abase + nc0, p.a.T, avalid, MT, WT_NTC, WT_NTC, 0, tid);
-    tile_issue<XVN>(xr, xbase + nc0 + p.lo, p.x.T, xvalid, CT, p.span, p.span, 0, tid);
-  };
-  bool have = false;
-  if (tile0 < tile_end && simple && chunk_fast(tile0)) { issue(tile0); have = true; }
-
-  for (int tile = tile0; tile < tile_end; ++tile) {
-    const int nc0 = tile * WT_NTC;
-    __syncthreads();
-    if (have) {
-      tile_commit<AV>(ar, nullptr, nullptr, p.a.xf, as, WT_AS, avalid, MT, WT_NTC, 0, tid);
-      tile_commit<XVN>(xr, nullptr, nullptr, p.x.xf, xs, WT_XS, xvalid, CT, p.span, 0, tid);
+  RegTile<AVV> ar; RegTile<XVV> xr;
+  RegS<AS_N> as_r, as_a; RegS<XS_N> xs_r;
+  auto issue = [&](int q, int mode) {
+    const int b = q / p.ntiles, nc0 = (q % p.ntiles) * WT_NTC;
+    const float* abase = p.a.p + (long)b * p.a.bs + (long)r0 * p.a.T;
+    const float* xbase = p.x.p + (long)b * p.x.bs + (long)c0 * p.x.T;
+    if (!SCAL) {
+      tile_issue<AVV>(ar, abase + nc0, p.a.T, avalid, MT, WT_NTC, WT_NTC, 0, tid);
+      tile_issue<XVV>(xr, xbase + nc0 + p.lo, p.x.T, xvalid, CT, p.span, p.span, 0, tid);
     } else {
-      if (p.vec && nc0 + WT_NTC <= p.N) stage_rows_batched<4>(p.a, as, WT_AS, b, r0, avalid, MT, nc0, WT_NTC, p.R, tid);
-      else {
-        for (int m = wave; m < MT; m += 4) {
-          float* dst = as + m * WT_AS;
-          for (int i = lane; i < WT_NTC; i += 64) {
-            const int n = nc0 + i;
-            dst[i] = (r0 + m < p.R && n < p.N) ? fetch_opnd(p.a, b, r0 + m, n, 0, p.R) : 0.f;
-          }
+      tile_issue_s<AS_N>(as_r, abase, p.N, avalid, MT, WT_NTC, nc0, 0, tid);
+      if (akind == XF_MASK_LRELU)
+        tile_issue_s<AS_N>(as_a, p.a.xf.aux + (long)b * p.a.xf.aux_bs + (long)r0 * p.a.T, p.N, avalid, MT, WT_NTC, nc0, 0, tid);
+      tile_issue_s<XS_N>(xs_r, xbase, p.x.T, xvalid, CT, p.span, nc0 + p.lo, p.reflect, tid);
+    }
+  };
+  int mode = (q_begin < q_end) ? chunk_mode(q_begin) : 0;
+  if (mode) issue(q_begin, mode);
+
+  for (int q = q_begin; q < q_end; ++q) {
+    const int b = q / p.ntiles, nc0 = (q % p.ntiles) * WT_NTC;
+    __syncthreads();
+    if (!SCAL && mode == 2) {
+      tile_commit<AVV>(ar, nullptr, nullptr, p.a.xf, as, WT_AS, avalid, MT, WT_NTC, 0, tid);
+      tile_commit<XVV>(xr, nullptr, nullptr, p.x.xf, xs, WT_XS, xvalid, CT, p.span, 0, tid);
+    } else if (SCAL && mode == 1) {
+      tile_commit_s<AS_N>(as_r, &as_a, p.a.xf, as, WT_AS, MT, WT_NTC, tid);
+      tile_commit_s<XS_N>(xs_r, nullptr, p.x.xf, xs, WT_XS, CT, p.span, tid);
+    } else {
+      for (int m = wave; m < MT; m += 4) {
+        float* dst = as + m * WT_AS;
+        for (int i = lane; i < WT_NTC; i += 64) {
+          const int n = nc0 + i;
+          dst[i] = (r0 + m < p.R && n < p.N) ? fetch_opnd(p.a, b, r0 + m, n, 0, p.R) : 0.f;
         }
       }
-      if (p.vec && nc0 + p.lo >= 0 && nc0 + p.lo + p.span <= p.x.T) stage_rows_batched<4>(p.x, xs, WT_XS, b, c0, xvalid, CT, nc0 + p.lo, p.span, p.Cin, tid);
-      else {
-        for (int r = wave; r < CT; r += 4) {
-          float* dst = xs + r * WT_XS;
-          for (int i = lane; i < p.span; i += 64) dst[i] = (c0 + r < p.Cin) ? fetch_opnd(p.x, b, c0 + r, nc0 + p.lo + i, p.reflect, p.Cin) : 0.f;
-        }
+      for (int r = wave; r < CT; r += 4) {
+        float* dst = xs + r * WT_XS;
+        for (int i = lane; i < p.span; i += 64) dst[i] = (c0 + r < p.Cin) ? fetch_opnd(p.x, b, c0 + r, nc0 + p.lo + i, p.reflect, p.Cin) : 0.f;
       }
     }
     __syncthreads();
-    have = false;
-    if (tile + 1 < tile_end && simple && chunk_fast(tile + 1)) { issue(tile + 1); have = true; }
+    mode = (q + 1 < q_end) ? chunk_mode(q + 1) : 0;
+    if (mode) issue(q + 1, mode);
 
     if (p.bias_off >= 0 && ct == 0) {
       for (int rr = tid >> 4; rr < MT; rr += 16) {
@@ -278,12 +292,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile_kernel(const WgLeanP p
           for (int j = 0; j < J; ++j)
             acc[m][c][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][m], bv[buf][c][j], acc[m][c][j], 0, 0, 0);
     };
+    const int ncols = min(WT_NTC, ((p.N - nc0) + 7) & ~7);      // skip the all-zero tail of a short last tile
     load_frag(0, 0);
 #pragma unroll 1
-    for (int nn = 0; nn < WT_NTC; nn += 8) {
+    for (int nn = 0; nn < ncols; nn += 8) {
       load_frag(1, nn + 4);
       mma(0);
-      if (nn + 8 < WT_NTC) load_frag(0, nn + 8);
+      if (nn + 8 < ncols) load_frag(0, nn + 8);
       mma(1);
     }
   }
@@ -314,13 +329,13 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile_kernel(const WgLeanP p
   }
 }
 
-template <int M_REP, int C_REP, int J, int D>
-static hipError_t wt_launch(const WgLeanP& p, int B, hipStream_t st) {
+template <int M_REP, int C_REP, int J, int D, bool SCAL>
+static hipError_t wt_launch2(const WgLeanP& p, int B, hipStream_t st) {
   constexpr int MT = 32 * M_REP, CT = 32 * C_REP;
-  auto k = conv_wgrad_tile_kernel<M_REP, C_REP, J, D>;
+  auto k = conv_wgrad_tile_kernel<M_REP, C_REP, J, D, SCAL>;
   static bool once = false;
   if (!once) { hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
-  dim3 grid(B * p.ngroups, ((p.R + MT - 1) / MT) * ((p.Cin + CT - 1) / CT), 1);
+  dim3 grid(p.ngroups, ((p.R + MT - 1) / MT) * ((p.Cin + CT - 1) / CT), 1);      // wide: ngroups counts (sample, tile) chunk groups
   const size_t lds = (size_t)(MT * WT_AS + CT * WT_XS) * sizeof(float);
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
   return hipGetLastError();
@@ -342,9 +357,17 @@ static hipError_t wg_launch(const WgLeanP& p, int B, hipStream_t st) {
 
 void wgrad_lean_plan(int R, int Cin, int N, int K, int B, int* ntiles, int* tpb, int* ngroups);
 
+template <int M_REP, int C_REP, int J, int D>
+static hipError_t wt_launch(const WgLeanP& p, int B, hipStream_t st) {
+  // aligned long sequences with plain prologues -> float4 prefetch; everything else -> scalar prefetch
+  const bool vec = p.vec && p.a.xf.kind <= XF_LRELU && p.x.xf.kind <= XF_LRELU && p.N >= 2 * WT_NTC;
+  return vec ? wt_launch2<M_REP, C_REP, J, D, false>(p, B, st) : wt_launch2<M_REP, C_REP, J, D, true>(p, B, st);
+}
+
 template <int J, int D>
 static hipError_t wg_launch_jd(WgLeanP& p, int B, hipStream_t st) {
   wgrad_lean_plan(p.R, p.Cin, p.N, p.K, B, &p.ntiles, &p.tpb, &p.ngroups);
+  p.B = B;
   if (p.R <= 16 || p.Cin <= 16) return wg_launch<1, 1, J, D>(p, B, st);
   // wide layers: 64-step chunks, register tile per wave
   p.span = ((WT_NTC + (J - 1) * D - p.pad - p.lo) + 3) / 4 * 4;
@@ -368,9 +391,23 @@ void wgrad_lean_plan(int R, int Cin, int N, int K, int B, int* ntiles, int* tpb,
   // prefetches across chunks, and fewer, longer blocks mean fewer partial slabs to write and fold
   int t = (int)(blocks / (narrow ? 1024 : 512));
   if (t < 1) t = 1;
-  if (t > *ntiles) t = *ntiles;
-  *tpb = t;
-  *ngroups = (*ntiles + t - 1) / t;
+  if (narrow) {                                  // groups per sample
+    if (t > *ntiles) t = *ntiles;
+    *tpb = t;
+    *ngroups = (*ntiles + t - 1) / t;
+  } else {                                       // groups over all B * ntiles (sample, tile) chunks
+    const long nchunks = (long)B * (*ntiles);
+    if (t > nchunks) t = (int)nchunks;
+    *tpb = t;
+    *ngroups = (int)((nchunks + t - 1) / t);
+  }
+}
+
+// slabs written by one launch
+int wgrad_lean_nslab(int R, int Cin, int N, int K, int B) {
+  int ntiles, tpb, ngroups;
+  wgrad_lean_plan(R, Cin, N, K, B, &ntiles, &tpb, &ngroups);
+  return (R <= 16 || Cin <= 16) ? B * ngroups : ngroups;
 }
 
 bool wgrad_lean_supported(int J, int D) {
