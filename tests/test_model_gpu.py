@@ -166,3 +166,28 @@ def test_split_conditioning_equals_dense(models, dev):
     errs = {k: rel_l2(res[True][1][k], g) for k, g in res[False][1].items()}
     worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
     assert worst[0][1] < 2e-4, worst
+
+
+def test_graph_replay_matches_eager(dev):
+    """The whole iteration captured into one hipGraph replays to the same losses / parameters as eager launches."""
+    P = pkg()
+    cfg = P.train_step.StepConfig()
+    bt = to_dev(P.synth.make_batch(2, 8960, seed=5), dev)
+    ix = P.synth.contrastive_indices(2, 28, cfg.n_neg, 1).to(dev)
+    iy = P.synth.contrastive_indices(2, 28, cfg.n_neg, 2).to(dev)
+    res = {}
+    for mode in ('eager', 'graph'):
+        G, D = build_models(dev)
+        ts = P.train_step.TrainStep(G, D, cfg, dev)
+        if mode == 'graph':
+            step = ts.capture(bt, ix, iy, warmup=2)       # 2 eager warm-up iterations (capture itself executes nothing)
+            for _ in range(2):
+                log = step()
+        else:
+            for _ in range(4):
+                log = ts.run(bt, ix, iy)
+        torch.cuda.synchronize()
+        res[mode] = ({k: float(v) for k, v in log.items()}, G.arena.P.detach().clone(), D.arena.P.detach().clone())
+    for k, v in res['eager'][0].items():
+        assert abs(res['graph'][0][k] - v) <= 1e-4 * (abs(v) + 1e-6), (k, res['graph'][0][k], v)
+    assert rel_l2(res['graph'][1], res['eager'][1]) < 1e-5 and rel_l2(res['graph'][2], res['eager'][2]) < 1e-5
