@@ -264,7 +264,7 @@ static bool wgrad_use_mfma(const WgradP& p) {
 static bool wgrad_lean_ok(const tdvc_conv_desc* d) {
   const bool wide = d->Cout >= 32 && d->Cin >= 32;     // register-tile kernel: walks (sample, tile) chunks, any length
   return !g_force_generic && d->kind == TDVC_CONV && d->stride == 1 && d->groups == 1 && d->Tin == d->Tout &&
-         (d->Tout > 128 || wide) && d->Cin >= 4 && wgrad_lean_supported(d->K, d->dilation);
+         (d->Tout > 128 || wide) && wgrad_lean_supported(d->K, d->dilation) && (d->K != 15 || d->Cout <= 16 || d->Cin <= 16);
 }
 
 namespace tdvc { int wgrad_lean_nslab(int R, int Cin, int N, int K, int B); }

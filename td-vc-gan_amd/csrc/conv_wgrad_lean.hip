@@ -369,6 +369,7 @@ static hipError_t wg_launch_jd(WgLeanP& p, int B, hipStream_t st) {
   wgrad_lean_plan(p.R, p.Cin, p.N, p.K, B, &p.ntiles, &p.tpb, &p.ngroups);
   p.B = B;
   if (p.R <= 16 || p.Cin <= 16) return wg_launch<1, 1, J, D>(p, B, st);
+  if (J == 15) return hipErrorNotSupported;      // 15-tap layers on the path are narrow (D layer 0: 1 -> 16)
   // wide layers: 64-step chunks, register tile per wave
   p.span = ((WT_NTC + (J - 1) * D - p.pad - p.lo) + 3) / 4 * 4;
   if (p.R <= 32) {
@@ -412,7 +413,7 @@ int wgrad_lean_nslab(int R, int Cin, int N, int K, int B) {
 
 bool wgrad_lean_supported(int J, int D) {
   if (J == 1) return D == 1;
-  if (J == 5) return D == 1;
+  if (J == 5 || J == 15) return D == 1;
   return (J == 3 || J == 7 || J == 11) && (D == 1 || D == 3 || D == 5);
 }
 
@@ -424,7 +425,7 @@ hipError_t launch_conv_wgrad_lean(WgLeanP p, int B, int J, int D, hipStream_t st
   p.span = ((WG_NTC + (J - 1) * D - p.pad - p.lo) + 3) / 4 * 4;
   if (p.span > WG_XS - 2) return hipErrorNotSupported;
 #define WG_CASE(JJ, DD) if (J == JJ && D == DD) return wg_launch_jd<JJ, DD>(p, B, st);
-  WG_CASE(1, 1) WG_CASE(5, 1)
+  WG_CASE(1, 1) WG_CASE(5, 1) WG_CASE(15, 1)
   WG_CASE(3, 1) WG_CASE(3, 3) WG_CASE(3, 5)
   WG_CASE(7, 1) WG_CASE(7, 3) WG_CASE(7, 5)
   WG_CASE(11, 1) WG_CASE(11, 3) WG_CASE(11, 5)

