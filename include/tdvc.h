@@ -106,6 +106,23 @@ size_t tdvc_conv_wgrad_workspace(const tdvc_conv_desc* d);
 /* Force the scalar (non-MFMA) kernels: used by tests to cross-check the two code paths. */
 void tdvc_set_force_generic(int on);
 
+/* Fused FiLM conditioning forward (model/generator.py:86-92, 103): gb = cond_var.2(LeakyReLU(cond_var.0(c))) with
+ * c = [speaker embedding (n_cond-n_var channels, constant in time) ; excitation (n_var channels)]. The time-constant part
+ * enters as k3 [B][n_cond][3] (= cond_var.0 restricted to the embedding channels, evaluated on a length-3 signal, bias
+ * included: left edge / interior / right edge); the excitation part is computed per tile in LDS, so the n_cond-channel
+ * intermediate is written once (cv0, for the backward pass; may be NULL) and never re-read by the forward. */
+typedef struct {
+  int32_t B, T, n_cond, n_var, C2;      /* C2 = 2 * n_channel (gamma and beta) */
+  const float* exc; int64_t exc_bs;     /* [B][n_var][T] */
+  const float* w0;                      /* cond_var.0 effective weight [n_cond][n_cond][3] */
+  const float* k3;                      /* [B][n_cond][3] */
+  const float* w2; const float* b2;     /* cond_var.2 effective weight [C2][n_cond][3], bias [C2] */
+  float* cv0; int64_t cv0_bs;           /* optional pre-activation cond_var.0 output [B][n_cond][T] */
+  float* gb; int64_t gb_bs;             /* [B][C2][T] */
+  float slope;
+} tdvc_film_cond_args;
+int tdvc_film_cond_fwd(const tdvc_film_cond_args* a, void* stream);
+
 /* Multi-tensor weight norm (old-style nn.utils.weight_norm, dim=0; model/generator.py:14,
  * util/__init__.py:16-20, model/discriminator.py:11): w[row] = g[row] * v[row] / ||v[row]||, one wave per
  * dim-0 slice, every weight-normed tensor of a model in ONE launch. `params` is the model's flat parameter

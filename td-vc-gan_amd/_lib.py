@@ -32,6 +32,13 @@ class ConvFwdArgs(C.Structure):
                 ('y_bs', C.c_int64), ('bias3', C.c_void_p)]
 
 
+class FilmCondArgs(C.Structure):
+    _fields_ = [('B', C.c_int32), ('T', C.c_int32), ('n_cond', C.c_int32), ('n_var', C.c_int32), ('C2', C.c_int32),
+                ('exc', C.c_void_p), ('exc_bs', C.c_int64), ('w0', C.c_void_p), ('k3', C.c_void_p),
+                ('w2', C.c_void_p), ('b2', C.c_void_p), ('cv0', C.c_void_p), ('cv0_bs', C.c_int64),
+                ('gb', C.c_void_p), ('gb_bs', C.c_int64), ('slope', C.c_float)]
+
+
 class ConvDgradArgs(C.Structure):
     _fields_ = [('dy', C.c_void_p), ('dy_bs', C.c_int64), ('dy_xf', Xform), ('w', C.c_void_p), ('wt', C.c_void_p),
                 ('epilogue', C.c_int32), ('x_in', C.c_void_p), ('x_in_bs', C.c_int64), ('slope', C.c_float),
@@ -58,6 +65,7 @@ SIGNATURES = {
     'tdvc_conv_dgrad': (_i, [C.POINTER(ConvDesc), C.POINTER(ConvDgradArgs), _vp]),
     'tdvc_conv_wgrad': (_i, [C.POINTER(ConvDesc), C.POINTER(ConvWgradArgs), _vp]),
     'tdvc_conv_wgrad_workspace': (C.c_size_t, [C.POINTER(ConvDesc)]),
+    'tdvc_film_cond_fwd': (_i, [C.POINTER(FilmCondArgs), _vp]),
     'tdvc_set_force_generic': (None, [_i]),
     'tdvc_weight_norm_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'tdvc_weight_norm_fwd_t': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),

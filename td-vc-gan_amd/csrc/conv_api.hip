@@ -26,10 +26,13 @@ struct LeanP {
   int T, Cin, Cout, Cw, K, d, pad, flip, reflect, mirror;
   int Cc, span, lo, i0, XS, WS;
   int post;
+  const float* cw; const float* k3; float* cv0;
+  int cw_stride, Cv, cv0_bs, ES;
   int vec;
   float slope, in_scale, out_scale, add_scale, m_slope;
 };
 hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st);
+hipError_t launch_conv_lean_cond(LeanP p, int B, hipStream_t st);
 struct WgLeanP {
   Opnd a; Opnd x;
   int R, Cin, N, pad, K, reflect, B;
@@ -340,4 +343,22 @@ extern "C" int tdvc_conv_wgrad(const tdvc_conv_desc* d, const tdvc_conv_wgrad_ar
     if (e != hipSuccess) return tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));
   }
   return TDVC_OK;
+}
+
+
+// FiLM conditioning forward (model/generator.py:86-92,103-104): gb = cond_var.2(LeakyReLU(cond_var.0(c))), where
+// cond_var.0 is evaluated as [time-constant speaker part = k3] + [n_var-channel excitation window of its weight].
+extern "C" int tdvc_film_cond_fwd(const tdvc_film_cond_args* a, void* stream) {
+  if (!a || !a->exc || !a->w0 || !a->k3 || !a->w2 || !a->gb) return tdvc_fail(TDVC_EINVAL, "film_cond_fwd: null pointer");
+  if (a->B <= 0 || a->T < 4 || a->n_cond <= a->n_var || a->n_var <= 0 || a->C2 <= 0) return tdvc_fail(TDVC_EINVAL, "film_cond_fwd: bad shape");
+  LeanP q = {};
+  q.x = a->exc; q.x_bs = (int)a->exc_bs; q.w = a->w2; q.bias = a->b2; q.y = a->gb; q.y_bs = (int)a->gb_bs;
+  q.T = a->T; q.Cin = a->n_cond; q.Cout = a->C2; q.Cw = a->n_cond * 3; q.K = 3; q.d = 1; q.pad = 1;
+  q.cw = a->w0 + (long)(a->n_cond - a->n_var) * 3; q.cw_stride = a->n_cond * 3; q.Cv = a->n_var;
+  q.k3 = a->k3; q.cv0 = a->cv0; q.cv0_bs = (int)a->cv0_bs;
+  q.slope = a->slope; q.in_scale = 1.f; q.out_scale = 1.f; q.add_scale = 1.f; q.m_slope = a->slope; q.post = TDVC_POST_NONE;
+  q.vec = ((a->T & 3) == 0 && vec_ptr(a->gb, a->gb_bs) && vec_ptr(a->cv0, a->cv0_bs) && al16(a->w2) && ((a->n_cond * 3) & 3) == 0) ? 1 : 0;
+  hipError_t e = launch_conv_lean_cond(q, a->B, (hipStream_t)stream);
+  if (e == hipErrorNotSupported) return tdvc_fail(TDVC_EUNSUPPORTED, "film_cond_fwd: shape outside the fused kernel's contract");
+  return e == hipSuccess ? TDVC_OK : tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));
 }

@@ -15,7 +15,11 @@ namespace tdvc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { LXF_ACT = 0, LXF_FILM = 1, LXF_MASK_LRELU = 2, LXF_MASK_TANH = 3 };   // prologue kinds (ACT: none or LeakyReLU by slope)
+enum { LXF_ACT = 0, LXF_FILM = 1, LXF_MASK_LRELU = 2, LXF_MASK_TANH = 3, LXF_COND = 4 };   // prologue kinds (ACT: none or LeakyReLU by slope)
+// LXF_COND: the input tile is not loaded but COMPUTED in the block: rows = channels of FiLM's cond_var.0 output
+//   cv0[c][t] = sum_{ce,j} W0x[c][ce][j] * exc[ce][t+j-1] + k3[b][c][edge(t)]   (8 excitation channels, 3 taps, K = 24)
+// as a small MFMA pre-pass per channel chunk, LeakyReLU'd straight into the LDS tile that cond_var.2 then convolves;
+// the 136-channel intermediate is written once (for the backward pass) and never read back by the forward.
 
 struct LeanP {
   const float* x; const float* w; float* y;
@@ -26,6 +30,8 @@ struct LeanP {
   int T, Cin, Cout, Cw, K, d, pad, flip, reflect, mirror;
   int Cc, span, lo, i0, XS, WS;
   int post;
+  const float* cw; const float* k3; float* cv0;   // LXF_COND: cond_var.0 excitation-window weights, edge bias, cv0 output
+  int cw_stride, Cv, cv0_bs, ES;
   int vec;                             // host-checked: T % 4 == 0, every pointer 16-byte aligned, batch strides % 4 == 0
   float slope, in_scale, out_scale, add_scale, m_slope;
 };
@@ -57,6 +63,9 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 2 : (M_REP * N_REP >= 8
   constexpr int WVV = MT >= 48 ? 10 : (MT >= 32 ? 6 : 3);
   float* xs = smem;
   float* ws = smem + p.Cc * p.XS;
+  constexpr int WX = 25;                                  // odd row stride of the staged W0x chunk
+  float* es = ws + MT * p.WS;                             // LXF_COND: excitation tile [Cv][ES]
+  float* wx = es + p.Cv * p.ES;                           // LXF_COND: W0x chunk [Cc][WX]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
@@ -72,19 +81,27 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 2 : (M_REP * N_REP >= 8
 
   const int q0 = n0 + p.lo;
   const bool vec_ok = p.vec != 0;                      // rows 16-byte aligned -> float4 staging / epilogue
-  const bool interior = vec_ok && q0 >= 0 && q0 + p.span <= p.T;
+  const bool interior = (XFK != LXF_COND) && vec_ok && q0 >= 0 && q0 + p.span <= p.T;
   const int jc = p.K * p.Cc;
   const float* xrow0 = p.x + (long)b * p.x_bs + q0;
-  const float* arow0 = (XFK != LXF_ACT) ? p.aux + (long)b * p.aux_bs + q0 : nullptr;
+  const float* arow0 = (XFK != LXF_ACT && XFK != LXF_COND) ? p.aux + (long)b * p.aux_bs + q0 : nullptr;
   const float* wgrow = p.w + (long)r0 * p.Cw;
   const int mvalid = min(MT, p.Cout - r0);
-  Xf xf; xf.kind = (XFK == LXF_ACT) ? XF_LRELU : (XFK == LXF_FILM ? XF_FILM_LRELU : (XFK == LXF_MASK_LRELU ? XF_MASK_LRELU : XF_MASK_TANH));
+  Xf xf; xf.kind = (XFK == LXF_ACT || XFK == LXF_COND) ? XF_LRELU : (XFK == LXF_FILM ? XF_FILM_LRELU : (XFK == LXF_MASK_LRELU ? XF_MASK_LRELU : XF_MASK_TANH));
   xf.slope = p.slope; xf.scale = p.in_scale; xf.aux = nullptr; xf.aux_bs = 0;
   const Xf wxf = {XF_NONE, 0.f, 1.f, nullptr, 0};
 
   RegTile<XV> xr;
   RegTile<WVV> wr;
   const bool xpipe = (XFK == LXF_ACT) && interior;
+  if (XFK == LXF_COND) {   // excitation tile: positions q0-1 .. q0+span, zero outside the sequence ('same' zero padding)
+    const float* eb = p.x + (long)b * p.x_bs;
+    for (int r = wave; r < p.Cv; r += 4)
+      for (int i = lane; i < p.span + 2; i += 64) {
+        const int pos = q0 - 1 + i;
+        es[r * p.ES + i] = (pos >= 0 && pos < p.T) ? eb[(long)r * p.T + pos] : 0.f;
+      }
+  }
   auto x_issue = [&](int c0) { tile_issue<XV>(xr, xrow0 + (long)c0 * p.T, p.T, min(p.Cc, p.Cin - c0), p.Cc, p.span, p.span, 0, tid); };
   auto w_issue = [&](int c0) { tile_issue<WVV>(wr, wgrow + (long)c0 * p.K, p.Cw, mvalid, MT, jc, min(p.Cc, p.Cin - c0) * p.K, 0, tid); };
   if (xpipe) x_issue(0);
@@ -100,14 +117,68 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 2 : (M_REP * N_REP >= 8
   for (int c0 = 0; c0 < p.Cin; c0 += p.Cc) {
     const int cvalid = min(p.Cc, p.Cin - c0);
     __syncthreads();
-    if (xpipe) {
+    if (XFK == LXF_COND) {
+      // stage this chunk's W0x rows, then compute lrelu(cv0) for the chunk with MFMA: D[t][c] = E[t][k] * W0x[k][c]
+      const int kv = p.Cv * 3;
+      for (int idx = tid; idx < p.Cc * kv; idx += 256) {
+        const int c = idx / kv, k = idx - c * kv;
+        wx[c * WX + k] = (c < cvalid) ? p.cw[(long)(c0 + c) * p.cw_stride + k] : 0.f;
+      }
+      __syncthreads();
+      const int ntl = p.Cc >> 4;                          // channel tiles of 16 (Cc is 16 or 32)
+      float k3v[2][3];
+#pragma unroll
+      for (int nt = 0; nt < 2; ++nt) {
+        const int c = c0 + nt * 16 + ln;
+        const bool cv = nt < ntl && (nt * 16 + ln) < cvalid;
+#pragma unroll
+        for (int e = 0; e < 3; ++e) k3v[nt][e] = cv ? p.k3[((long)b * p.Cin + c) * 3 + e] : 0.f;
+      }
+      const int mtl = (p.span + 15) >> 4;
+      for (int mtile = wave; mtile < mtl; mtile += 4) {
+        f32x4 pa[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
+        for (int st = 0; st * 4 < kv; ++st) {
+          const int k = st * 4 + kq;
+          const int ce = k / 3, j = k - ce * 3;
+          const float a = (k < kv) ? es[ce * p.ES + mtile * 16 + ln + j] : 0.f;
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            if (nt >= ntl) continue;
+            const float bw = (k < kv) ? wx[(nt * 16 + ln) * WX + k] : 0.f;
+            pa[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw, pa[nt], 0, 0, 0);
+          }
+        }
+        const int t0 = mtile * 16 + kq * 4;                 // lane owns 4 consecutive positions of channel (nt*16 + ln)
+        if (t0 < p.span) {
+#pragma unroll
+          for (int nt = 0; nt < 2; ++nt) {
+            if (nt >= ntl) continue;
+            const int cl = nt * 16 + ln;
+            f32x4 raw, act;
+#pragma unroll
+            for (int r = 0; r < 4; ++r) {
+              const int pos = q0 + t0 + r;
+              const bool inside = pos >= 0 && pos < p.T && cl < cvalid;
+              const float v = pa[nt][r] + (pos == 0 ? k3v[nt][0] : (pos == p.T - 1 ? k3v[nt][2] : k3v[nt][1]));
+              raw[r] = inside ? v : 0.f;
+              act[r] = inside ? fmaxf(v, v * p.slope) * p.in_scale : 0.f;
+            }
+            *reinterpret_cast<f32x4*>(xs + cl * p.XS + t0) = act;
+            // the block row 0 of each time tile also materialises cv0 (own columns only) for the backward pass
+            const int pos0 = q0 + t0;
+            if (p.cv0 && blockIdx.y == 0 && cl < cvalid && pos0 >= n0 && pos0 < n0 + NT && pos0 < p.T)
+              *reinterpret_cast<f32x4*>(p.cv0 + (long)b * p.cv0_bs + (long)(c0 + cl) * p.T + pos0) = raw;
+          }
+        }
+      }
+    } else if (xpipe) {
       tile_commit<XV>(xr, nullptr, nullptr, xf, xs, p.XS, cvalid, p.Cc, p.span, 0, tid);
     } else if (interior) {
       const int total = p.Cc * (p.span >> 2);
       for (int eb = 0; eb < total; eb += XV * 256) {
         RegTile<XV> t, a, c;
         tile_issue<XV>(t, xrow0 + (long)c0 * p.T, p.T, cvalid, p.Cc, p.span, p.span, eb, tid);
-        if (XFK != LXF_ACT) tile_issue<XV>(a, arow0 + (long)c0 * p.T, p.T, cvalid, p.Cc, p.span, p.span, eb, tid);
+        if (XFK != LXF_ACT && XFK != LXF_COND) tile_issue<XV>(a, arow0 + (long)c0 * p.T, p.T, cvalid, p.Cc, p.span, p.span, eb, tid);
         if (XFK == LXF_FILM) tile_issue<XV>(c, arow0 + (long)(p.Cin + c0) * p.T, p.T, cvalid, p.Cc, p.span, p.span, eb, tid);
         tile_commit<XV>(t, &a, &c, xf, xs, p.XS, cvalid, p.Cc, p.span, eb, tid);
       }
@@ -115,7 +186,7 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 2 : (M_REP * N_REP >= 8
       for (int r = wave; r < p.Cc; r += 4) {
         float* row = xs + r * p.XS;
         const bool rv = r < cvalid;
-        for (int i = lane; i < p.span; i += 64) row[i] = rv ? lean_fetch<XFK>(p, b, c0 + r, q0 + i) : 0.f;
+        for (int i = lane; i < p.span; i += 64) row[i] = rv ? lean_fetch<(XFK == LXF_COND ? LXF_ACT : XFK)>(p, b, c0 + r, q0 + i) : 0.f;
       }
     }
     tile_commit<WVV>(wr, nullptr, nullptr, wxf, ws, p.WS, mvalid, MT, jc, 0, tid);
@@ -326,6 +397,39 @@ static hipError_t lean_launch2(const LeanP& p, int B, int xfk, int epi, hipStrea
   if (xfk == LXF_ACT && epi == EPI_PLAIN) return lean_launch3<M_REP, N_REP, WM, WN, LXF_ACT, EPI_PLAIN>(p, B, st);
   if (xfk == LXF_MASK_LRELU && epi == EPI_PLAIN) return lean_launch3<M_REP, N_REP, WM, WN, LXF_MASK_LRELU, EPI_PLAIN>(p, B, st);
   return hipErrorNotSupported;
+}
+
+// FiLM conditioning forward: gb = cond_var.2(lrelu(cond_var.0(c))) with the cond_var.0 output computed per tile in
+// LDS (LXF_COND). p.x = excitation [B][Cv][T]; p.Cin = channels of cv0 (= Cin of cond_var.2); p.w = cond_var.2 weight.
+hipError_t launch_conv_lean_cond(LeanP p, int B, hipStream_t st) {
+  if ((p.T & 3) || !p.vec || p.K != 3 || p.d != 1 || p.pad != 1 || p.Cv * 3 > 24) return hipErrorNotSupported;
+  const int MT = p.Cout <= 32 ? 32 : 64, NT = 256;
+  p.mirror = 0; p.flip = 0; p.reflect = 0;
+  const int first = -p.pad;
+  const int lo = -4;                                   // aligned origin
+  p.lo = lo; p.i0 = first - lo;
+  p.span = ((NT + (p.K - 1) * p.d - p.pad - lo) + 3) / 4 * 4;
+  p.XS = ((p.span + 31) / 32) * 32 + 16;
+  p.ES = ((p.span + 15) / 16) * 16 + 4;
+  const int wvv = MT >= 48 ? 10 : 6;
+  int Cc = 32;
+  if ((size_t)(Cc * p.XS + MT * (p.K * Cc + 2) + p.Cv * p.ES + Cc * 25) * 4 > 80 * 1024 || (long)MT * p.K * Cc > wvv * 1024) Cc = 16;
+  p.Cc = Cc;
+  p.WS = p.K * Cc + 2;
+  const size_t lds = (size_t)(Cc * p.XS + MT * p.WS + p.Cv * p.ES + Cc * 25) * sizeof(float);
+  dim3 grid((p.T + NT - 1) / NT, (p.Cout + MT - 1) / MT, B);
+  if (MT == 32) {
+    auto k = conv_lean_kernel<2, 4, 1, 4, LXF_COND, EPI_FWD>;
+    static bool once = false;
+    if (!once) { lean_big_lds(k); once = true; }
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
+  } else {
+    auto k = conv_lean_kernel<4, 4, 1, 4, LXF_COND, EPI_FWD>;
+    static bool once = false;
+    if (!once) { lean_big_lds(k); once = true; }
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
+  }
+  return hipGetLastError();
 }
 
 // Returns hipErrorNotSupported when the shape/variant is outside the lean kernel's contract.

@@ -153,6 +153,9 @@ class ArenaModule(nn.Module):
 
 
 # ------------------------------------------------------------------------------- generator blocks
+FUSED_COND = True      # cond_var.0 -> LeakyReLU -> cond_var.2 in one forward launch (ops.FilmCondFn)
+
+
 class FiLMResnetBlock(nn.Module):
     def __init__(self, n_channel, n_cond_const, n_cond_var=0, dilation=1, kernel_size=3):
         super().__init__()
@@ -184,8 +187,11 @@ class FiLMResnetBlock(nn.Module):
         if isinstance(c, tuple):
             emb3, exc = c
             k3 = ops.conv(emb3, self.spec_const)
-            cv = ops.conv(exc, self.spec_var, k3=k3)
-            gb = self.cond_var[2](cv, pre=PRE_LRELU)
+            if FUSED_COND and exc.shape[2] % 4 == 0:
+                gb = ops.film_cond(exc, k3, self.spec_var, self.cond_var[2].spec)
+            else:
+                cv = ops.conv(exc, self.spec_var, k3=k3)
+                gb = self.cond_var[2](cv, pre=PRE_LRELU)
         elif c is not None:
             cv = self.cond_var[0](c)
             gb = self.cond_var[2](cv, pre=PRE_LRELU)

@@ -233,6 +233,44 @@ class FilmBlockFn(Function):
         return dx, dgb, (d_out if ctx.has_acc else None), None, None, None, None
 
 
+class FilmCondFn(Function):
+    """gb = cond_var.2(LeakyReLU(cond_var.0([emb; exc]))) (model/generator.py:86-92,103) in one forward launch:
+    the time-constant embedding part enters as k3 [B,nc,3], the excitation part of cond_var.0 is an MFMA pre-pass
+    that fills cond_var.2's LDS input tile directly. The nc-channel intermediate is written once for the backward
+    (which is the unfused chain) and not re-read by the forward."""
+
+    @staticmethod
+    def forward(ctx, exc, k3, token, spec_var, spec2):
+        exc, k3 = exc.contiguous(), k3.contiguous()
+        B, nv, T = exc.shape
+        nc = spec2.cin
+        cv0 = torch.empty((B, nc, T), dtype=torch.float32, device=exc.device)
+        gb = torch.empty((B, spec2.cout, T), dtype=torch.float32, device=exc.device)
+        a = L.FilmCondArgs(B, T, nc, nv, spec2.cout, exc.data_ptr(), _bs(exc), spec_var.slot.w, k3.data_ptr(),
+                           spec2.slot.w, spec2.slot.b or None, cv0.data_ptr(), _bs(cv0), gb.data_ptr(), _bs(gb), SLOPE)
+        L.check(L.lib().tdvc_film_cond_fwd(C.byref(a), _stream(exc)))
+        ctx.sv, ctx.s2 = spec_var, spec2
+        ctx.save_for_backward(exc, cv0)
+        return gb
+
+    @staticmethod
+    def backward(ctx, dgb):
+        exc, cv0 = ctx.saved_tensors
+        dgb = dgb.contiguous()
+        B, nc, T = cv0.shape
+        conv_wgrad_raw(ctx.s2, cv0, _xf(L.XF_LRELU), dgb, _xf())
+        dcv = conv_dgrad_raw(ctx.s2, dgb, _xf(), T, L.DG_MASK_LRELU, x_in=cv0)
+        conv_wgrad_raw(ctx.sv, exc, _xf(), dcv, _xf())
+        dexc = conv_dgrad_raw(ctx.sv, dcv, _xf(), T, L.DG_PLAIN) if ctx.needs_input_grad[0] else None
+        dk3 = torch.empty((B, nc, 3), dtype=torch.float32, device=dgb.device)
+        L.check(L.lib().tdvc_edge_sum3(dcv.data_ptr(), dk3.data_ptr(), B, nc, T, _stream(dgb)))
+        return dexc, dk3, None, None, None
+
+
+def film_cond(exc, k3, spec_var, spec2):
+    return FilmCondFn.apply(exc, k3, _token(spec_var, spec2), spec_var, spec2)
+
+
 def film_block(x, gb, acc, conv_spec, pos_spec, scale):
     return FilmBlockFn.apply(x, gb, acc, _token(conv_spec, pos_spec), conv_spec, pos_spec, scale)
 

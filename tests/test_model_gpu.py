@@ -168,6 +168,28 @@ def test_split_conditioning_equals_dense(models, dev):
     assert worst[0][1] < 2e-4, worst
 
 
+def test_fused_conditioning_equals_unfused(models, dev):
+    """tdvc_film_cond_fwd (cond_var.0 evaluated inside cond_var.2's forward kernel) against the two-launch chain."""
+    G, _ = models
+    M = pkg().modules
+    bt = to_dev(pkg().synth.make_batch(2, 8960, seed=22), dev)
+    res = {}
+    try:
+        for fused in (False, True):
+            M.FUSED_COND = fused
+            G.arena.zero_grad()
+            y, subs = G(bt['signal_real'], bt['c_tgt'], c_var=bt['c_f0_conv'], out_subsample=True)
+            (y.square().mean() + subs[0].mean() + subs[1].square().mean()).backward()
+            torch.cuda.synchronize()
+            res[fused] = (y.detach().clone(), {k: p.grad.detach().clone() for k, p in G.named_parameters() if p.grad is not None})
+    finally:
+        M.FUSED_COND = True
+    assert rel_l2(res[True][0], res[False][0]) < 1e-5
+    errs = {k: rel_l2(res[True][1][k], g) for k, g in res[False][1].items()}
+    worst = sorted(errs.items(), key=lambda kv: -kv[1])[:5]
+    assert worst[0][1] < 2e-4, worst
+
+
 def test_graph_replay_matches_eager(dev):
     """The whole iteration captured into one hipGraph replays to the same losses / parameters as eager launches."""
     P = pkg()
