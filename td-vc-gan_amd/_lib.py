@@ -8,7 +8,7 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, 'csrc', 'libtdvc_hip.so')
+LIB_PATH = os.environ.get('TDVC_HIP_LIB') or os.path.join(_HERE, 'csrc', 'libtdvc_hip.so')   # override: A/B builds in tools/
 
 c_float_p = C.POINTER(C.c_float)
 

@@ -2,6 +2,7 @@
 // reduced stride-1 problem of conv_common.h and picks the MFMA or the scalar kernel.
 #include "../../include/tdvc.h"
 #include "conv_common.h"
+#include "conv_lean.h"
 #include "api_util.h"
 
 namespace tdvc {
@@ -16,23 +17,7 @@ hipError_t launch_bias_grad(const Opnd&, int, int, int, float*, hipStream_t);
 }  // namespace tdvc
 
 namespace tdvc {
-enum { LXF_ACT = 0, LXF_FILM = 1, LXF_MASK_LRELU = 2, LXF_MASK_TANH = 3 };
-struct LeanP {
-  const float* x; const float* w; float* y;
-  const float* bias; const float* bias3; const float* res; const float* add;
-  const float* aux;
-  const float* mx; const float* gb; float* dgb;
-  int x_bs, y_bs, res_bs, add_bs, aux_bs, mx_bs, gb_bs, dgb_bs;
-  int T, Cin, Cout, Cw, K, d, pad, flip, reflect, mirror;
-  int Cc, span, lo, i0, XS, WS;
-  int post;
-  const float* cw; const float* k3; float* cv0;
-  int cw_stride, Cv, cv0_bs, ES;
-  int vec;
-  float slope, in_scale, out_scale, add_scale, m_slope;
-};
-hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st);
-hipError_t launch_conv_lean_cond(LeanP p, int B, hipStream_t st);
+
 struct WgLeanP {
   Opnd a; Opnd x;
   int R, Cin, N, pad, K, reflect, B;

@@ -167,6 +167,86 @@ __device__ __forceinline__ void tile_commit(const RegTile<NV>& t, const RegTile<
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Row-walk staging. A tile of `nrows` rows x `nvec` float4 columns (rows `rowstride` floats apart in HBM, `ls` floats
+// apart in LDS) is covered in passes of rp = 256 / nvec whole rows: thread (rsub, vv) touches row i*rp + rsub, column
+// vv in pass i, so consecutive passes differ by a wave-uniform stride and the per-element cost is one buffer load,
+// one add and one LDS store. Loads go through a raw buffer descriptor whose range check returns zero past the end of
+// the tensor (cdna_hip_programming.md T8); threads beyond rp*nvec carry an out-of-range offset.
+typedef __amdgpu_buffer_rsrc_t srd_t;
+typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ srd_t make_srd(const float* base, int bytes) {   // wave-uniform inputs only
+  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes > 0 ? bytes : 0, 0x00020000);
+}
+__device__ __forceinline__ f32x4_t buf_load4(srd_t rs, int voff) {
+  return __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
+}
+
+struct RowWalk { int voff, loff, gstep, lstep; bool active; };
+
+// The pass-count guards are loop invariant; hidden from LICM they stay one s_cmp + branch each instead of a table
+// of precomputed lane masks that spills out of the SGPR file.
+__device__ __forceinline__ int walk_opaque(int n) { asm volatile("" : "+s"(n)); return n; }
+
+// q0 / T: the tile's first column sits at position q0 of rows T long; columns outside [0, T) load as zero.
+__device__ __forceinline__ RowWalk make_walk(int tid, int nvec, int rp, int rowstride, int ls, int q0, int T) {
+  RowWalk w;
+  const int rsub = (int)(((float)tid + 0.5f) * (1.0f / (float)nvec));
+  const int vv = tid - rsub * nvec;
+  const int q = q0 + 4 * vv;
+  w.active = rsub < rp;
+  w.voff = (w.active && q >= 0 && q < T) ? (rsub * rowstride + q) * 4 : 0x7f000000;
+  w.loff = rsub * ls + 4 * vv;
+  w.gstep = rp * rowstride * 4;
+  w.lstep = rp * ls;
+  return w;
+}
+
+template <int NP>
+__device__ __forceinline__ void walk_issue(RegTile<NP>& t, srd_t rs, const RowWalk& w, int np) {
+  int vo = w.voff;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    if (i < walk_opaque(np)) { t.v[i] = buf_load4(rs, vo); vo += w.gstep; }
+  }
+}
+
+// Input tile: LeakyReLU (slope 1 = identity) and scale on the way into LDS; rows are 16-byte aligned (ls % 4 == 0).
+// The activation is applied in place so that every LDS store has its own source registers (no store-to-store waits).
+template <int NP>
+__device__ __forceinline__ void walk_commit_act(RegTile<NP>& t, const RowWalk& w, int np, float* lds, float slope, float scale) {
+  if (!w.active) return;
+  const int base = w.loff;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    if (i < walk_opaque(np)) {
+      f32x4_t o;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) { const float v = t.v[i][q]; o[q] = fmaxf(v, v * slope); }
+      if (scale != 1.f) o *= scale;
+      *reinterpret_cast<f32x4_t*>(lds + base + i * w.lstep) = o;
+      __builtin_amdgcn_sched_barrier(0);                 // one element at a time: keeps the temporaries to one float4
+    }
+  }
+}
+
+// Weight tile: rows are only 8-byte aligned in LDS (row stride K*Cc + 2 keeps the fragment reads conflict-free).
+template <int NP>
+__device__ __forceinline__ void walk_commit_w(const RegTile<NP>& t, const RowWalk& w, int np, float* lds) {
+  typedef float f32x2_t __attribute__((ext_vector_type(2)));
+  if (!w.active) return;
+  const int base = w.loff;
+#pragma unroll
+  for (int i = 0; i < NP; ++i) {
+    if (i < walk_opaque(np)) {
+      f32x2_t* d2 = reinterpret_cast<f32x2_t*>(lds + base + i * w.lstep);
+      d2[0] = (f32x2_t){t.v[i][0], t.v[i][1]};
+      d2[1] = (f32x2_t){t.v[i][2], t.v[i][3]};
+    }
+  }
+}
+
 // Whole tile, not pipelined: batches of NV float4 per thread (x up to 3 source tensors) in flight at a time.
 template <int NV>
 __device__ __forceinline__ void stage_rows_batched(const Opnd& o, float* dst, int XS, int b, int ch0, int nvalid, int nrows,

@@ -10,31 +10,34 @@
 //   * a compact parameter block (fits in SGPRs without spilling);
 //   * interior tiles stage through registers one channel chunk ahead of the MFMA loop (T14 split).
 #include "conv_common.h"
+#include "conv_lean.h"
 
 namespace tdvc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-enum { LXF_ACT = 0, LXF_FILM = 1, LXF_MASK_LRELU = 2, LXF_MASK_TANH = 3, LXF_COND = 4 };   // prologue kinds (ACT: none or LeakyReLU by slope)
+// prologue kinds LXF_* are declared in conv_lean.h (ACT: none or LeakyReLU by slope)
 // LXF_COND: the input tile is not loaded but COMPUTED in the block: rows = channels of FiLM's cond_var.0 output
 //   cv0[c][t] = sum_{ce,j} W0x[c][ce][j] * exc[ce][t+j-1] + k3[b][c][edge(t)]   (8 excitation channels, 3 taps, K = 24)
 // as a small MFMA pre-pass per channel chunk, LeakyReLU'd straight into the LDS tile that cond_var.2 then convolves;
 // the 136-channel intermediate is written once (for the backward pass) and never read back by the forward.
 
-struct LeanP {
-  const float* x; const float* w; float* y;
-  const float* bias; const float* bias3; const float* res; const float* add;
-  const float* aux;                    // prologue second tensor: FiLM gamma/beta or activation output
-  const float* mx; const float* gb; float* dgb;
-  int x_bs, y_bs, res_bs, add_bs, aux_bs, mx_bs, gb_bs, dgb_bs;
-  int T, Cin, Cout, Cw, K, d, pad, flip, reflect, mirror;
-  int Cc, span, lo, i0, XS, WS;
-  int post;
-  const float* cw; const float* k3; float* cv0;   // LXF_COND: cond_var.0 excitation-window weights, edge bias, cv0 output
-  int cw_stride, Cv, cv0_bs, ES;
-  int vec;                             // host-checked: T % 4 == 0, every pointer 16-byte aligned, batch strides % 4 == 0
-  float slope, in_scale, out_scale, add_scale, m_slope;
-};
+
+// Phase-cycle instrumentation for tools/lean_phase_prof.py (diagnostic build only: `make prof`; no stamp executes in the product .so).
+#ifdef LEAN_PROF
+__device__ unsigned long long* g_lean_prof = nullptr;
+#define PROF_DECL unsigned long long pt_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pl_ = __builtin_amdgcn_s_memtime(); const unsigned long long pr0_ = __builtin_amdgcn_s_memrealtime();
+#define PROF(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pt_[i] += n_ - pl_; pl_ = n_; }
+#define PROF_WAITV() __builtin_amdgcn_s_waitcnt(0x0f70);   /* vmcnt(0) only (gfx9 encoding: lgkmcnt/expcnt fields left at max) */
+#define PROF_END { pt_[7] = __builtin_amdgcn_s_memrealtime() - pr0_; if (g_lean_prof && threadIdx.x == 0) { \
+    unsigned long long* o_ = g_lean_prof + 10 * ((unsigned long long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x); \
+    for (int i_ = 0; i_ < 10; ++i_) o_[i_] = pt_[i_]; } }
+#else
+#define PROF_DECL
+#define PROF(i)
+#define PROF_WAITV()
+#define PROF_END
+#endif
 
 template <int XFK>
 __device__ __forceinline__ float lean_xform(const LeanP& p, float v, int b, int c, int q) {
@@ -56,15 +59,15 @@ __device__ __forceinline__ float lean_fetch(const LeanP& p, int b, int c, int q)
 }
 
 template <int M_REP, int N_REP, int WM, int WN, int XFK, int EPI>
-__global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 2 : (M_REP * N_REP >= 8 ? 3 : 4))) void conv_lean_kernel(const LeanP p) {
+__global__ __launch_bounds__(256, (M_REP * N_REP >= 12 ? 2 : ((M_REP * N_REP >= 8 || 16 * M_REP * WM >= 48) ? 3 : 4))) void conv_lean_kernel(const LeanP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int MT = 16 * M_REP * WM, NT = 16 * N_REP * WN;
-  constexpr int XV = (XFK == LXF_ACT) ? (MT >= 48 ? 8 : 6) : 4;      // float4 per thread per staged tensor
-  constexpr int WVV = MT >= 48 ? 10 : (MT >= 32 ? 6 : 3);
+  constexpr int XVP = MT >= 32 ? 12 : 6;                  // max row-walk passes of the prefetched input tile
+  constexpr int WVP = MT >= 48 ? 10 : (MT >= 32 ? 6 : 4);   // ... and of the weight tile
   float* xs = smem;
-  float* ws = smem + p.Cc * p.XS;
+  float* ws = smem + p.xnp * p.xrp * p.XS;
   constexpr int WX = 25;                                  // odd row stride of the staged W0x chunk
-  float* es = ws + MT * p.WS;                             // LXF_COND: excitation tile [Cv][ES]
+  float* es = ws + p.wnp * p.wrp * p.WS;                  // LXF_COND: excitation tile [Cv][ES]
   float* wx = es + p.Cv * p.ES;                           // LXF_COND: W0x chunk [Cc][WX]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -72,6 +75,7 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 2 : (M_REP * N_REP >= 8
   const int ln = lane & 15, kq = lane >> 4;
   const int n0 = blockIdx.x * NT, r0 = blockIdx.y * MT, b = blockIdx.z;
   const int wcol0 = wn * 16 * N_REP, wrow0 = wm * 16 * M_REP;
+  PROF_DECL
 
   f32x4 acc[M_REP][N_REP];
 #pragma unroll
@@ -81,18 +85,24 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 2 : (M_REP * N_REP >= 8
 
   const int q0 = n0 + p.lo;
   const bool vec_ok = p.vec != 0;                      // rows 16-byte aligned -> float4 staging / epilogue
-  const bool interior = (XFK != LXF_COND) && vec_ok && q0 >= 0 && q0 + p.span <= p.T;
+  // Every 16-byte-aligned tile is staged by the row walk, sequence ends included: a float4 column lies either wholly
+  // inside [0, T) or wholly outside (q0 % 4 == 0, T % 4 == 0), and outside columns carry an out-of-range offset, so
+  // the buffer loads return the zero padding. Reflect padding (forward trunk convs, ACT prologue only) is patched
+  // into the halo columns of the two end tiles after the commit.
+  const bool interior = (XFK != LXF_COND) && vec_ok && (XFK == LXF_ACT || !p.reflect);
+  const bool end_tile = q0 < 0 || q0 + p.span > p.T;
   const int jc = p.K * p.Cc;
-  const float* xrow0 = p.x + (long)b * p.x_bs + q0;
-  const float* arow0 = (XFK != LXF_ACT && XFK != LXF_COND) ? p.aux + (long)b * p.aux_bs + q0 : nullptr;
+  const float* xrow0 = p.x + (long)b * p.x_bs;
+  const float* arow0 = (XFK != LXF_ACT && XFK != LXF_COND) ? p.aux + (long)b * p.aux_bs : nullptr;
   const float* wgrow = p.w + (long)r0 * p.Cw;
-  const int mvalid = min(MT, p.Cout - r0);
-  Xf xf; xf.kind = (XFK == LXF_ACT || XFK == LXF_COND) ? XF_LRELU : (XFK == LXF_FILM ? XF_FILM_LRELU : (XFK == LXF_MASK_LRELU ? XF_MASK_LRELU : XF_MASK_TANH));
-  xf.slope = p.slope; xf.scale = p.in_scale; xf.aux = nullptr; xf.aux_bs = 0;
-  const Xf wxf = {XF_NONE, 0.f, 1.f, nullptr, 0};
 
-  RegTile<XV> xr;
-  RegTile<WVV> wr;
+  // Row-walk staging (conv_common.h): thread = (row of the pass, float4 column); a pass covers xrp (wrp) whole rows,
+  // so the per-element cost is one buffer load, one offset add and one LDS store -- no index arithmetic in the loop.
+  // Rows past the tensor end fall outside the descriptor's range and load as zero.
+  const RowWalk xw = make_walk(tid, p.span >> 2, p.xrp, p.T, p.XS, q0, p.T);
+  const RowWalk ww = make_walk(tid, jc >> 2, p.wrp, p.Cw, p.WS, 0, 1 << 30);
+  RegTile<XVP> xr;
+  RegTile<WVP> wr;
   const bool xpipe = (XFK == LXF_ACT) && interior;
   if (XFK == LXF_COND) {   // excitation tile: positions q0-1 .. q0+span, zero outside the sequence ('same' zero padding)
     const float* eb = p.x + (long)b * p.x_bs;
@@ -102,8 +112,14 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 2 : (M_REP * N_REP >= 8
         es[r * p.ES + i] = (pos >= 0 && pos < p.T) ? eb[(long)r * p.T + pos] : 0.f;
       }
   }
-  auto x_issue = [&](int c0) { tile_issue<XV>(xr, xrow0 + (long)c0 * p.T, p.T, min(p.Cc, p.Cin - c0), p.Cc, p.span, p.span, 0, tid); };
-  auto w_issue = [&](int c0) { tile_issue<WVV>(wr, wgrow + (long)c0 * p.K, p.Cw, mvalid, MT, jc, min(p.Cc, p.Cin - c0) * p.K, 0, tid); };
+  auto x_issue = [&](int c0) {
+    const srd_t rs = make_srd(xrow0 + (long)c0 * p.T, (p.Cin - c0) * p.T * 4);
+    walk_issue<XVP>(xr, rs, xw, p.xnp);
+  };
+  auto w_issue = [&](int c0) {
+    const srd_t rs = make_srd(wgrow + (long)c0 * p.K, ((p.Cout - r0) * p.Cw - c0 * p.K) * 4);
+    walk_issue<WVP>(wr, rs, ww, p.wnp);
+  };
   if (xpipe) x_issue(0);
   w_issue(0);
 
@@ -116,7 +132,11 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 2 : (M_REP * N_REP >= 8
 
   for (int c0 = 0; c0 < p.Cin; c0 += p.Cc) {
     const int cvalid = min(p.Cc, p.Cin - c0);
+    PROF(0)
     __syncthreads();
+    PROF(1)
+    PROF_WAITV()
+    PROF(8)
     if (XFK == LXF_COND) {
       // stage this chunk's W0x rows, then compute lrelu(cv0) for the chunk with MFMA: D[t][c] = E[t][k] * W0x[k][c]
       const int kv = p.Cv * 3;
@@ -172,15 +192,58 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 2 : (M_REP * N_REP >= 8
         }
       }
     } else if (xpipe) {
-      tile_commit<XV>(xr, nullptr, nullptr, xf, xs, p.XS, cvalid, p.Cc, p.span, 0, tid);
-    } else if (interior) {
-      const int total = p.Cc * (p.span >> 2);
-      for (int eb = 0; eb < total; eb += XV * 256) {
-        RegTile<XV> t, a, c;
-        tile_issue<XV>(t, xrow0 + (long)c0 * p.T, p.T, cvalid, p.Cc, p.span, p.span, eb, tid);
-        if (XFK != LXF_ACT && XFK != LXF_COND) tile_issue<XV>(a, arow0 + (long)c0 * p.T, p.T, cvalid, p.Cc, p.span, p.span, eb, tid);
-        if (XFK == LXF_FILM) tile_issue<XV>(c, arow0 + (long)(p.Cin + c0) * p.T, p.T, cvalid, p.Cc, p.span, p.span, eb, tid);
-        tile_commit<XV>(t, &a, &c, xf, xs, p.XS, cvalid, p.Cc, p.span, eb, tid);
+      walk_commit_act<XVP>(xr, xw, p.xnp, xs, p.slope, p.in_scale);
+      if (end_tile && p.reflect) {   // reflect halo of the first / last tile: columns with q < 0 or q >= T
+        const int nl = q0 < 0 ? -q0 : 0;
+        const int rfirst = p.T - q0;                       // first column index with q >= T
+        const int nr = rfirst < p.span ? p.span - rfirst : 0;
+        const int nh = nl + nr;
+        __syncthreads();                                   // the zero-filled halo columns were written by other threads
+        const float* xc = xrow0 + (long)c0 * p.T;
+        const float inv = 1.0f / (float)nh;
+        for (int e = tid; e < cvalid * nh; e += 256) {
+          const int r = (int)(((float)e + 0.5f) * inv);
+          const int h = e - r * nh;
+          const int i = h < nl ? h : rfirst + (h - nl);
+          int q = q0 + i;
+          q = q < 0 ? -q : 2 * (p.T - 1) - q;
+          float v = (q >= 0 && q < p.T) ? xc[(long)r * p.T + q] : 0.f;
+          v = (v > 0.f ? v : v * p.slope) * p.in_scale;
+          xs[r * p.XS + i] = v;
+        }
+      }
+    } else if (interior) {   // FiLM / activation-mask prologues: batches of 4 passes, up to three tensors in flight
+      const int xbytes = (p.Cin - c0) * p.T * 4;
+      const srd_t rx = make_srd(xrow0 + (long)c0 * p.T, xbytes);
+      const srd_t ra = make_srd(arow0 + (long)c0 * p.T, xbytes);
+      const srd_t rb = make_srd(arow0 + (long)(p.Cin + c0) * p.T, XFK == LXF_FILM ? xbytes : 0);
+      int vo = xw.voff;
+      float* dst = xs + xw.loff;
+      for (int pb = 0; pb < p.xnp; pb += 4) {
+        f32x4 t[4], a[4], c[4];
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (pb + i < p.xnp) {
+            t[i] = buf_load4(rx, vo); a[i] = buf_load4(ra, vo);
+            if (XFK == LXF_FILM) c[i] = buf_load4(rb, vo);
+            vo += xw.gstep;
+          }
+        }
+#pragma unroll
+        for (int i = 0; i < 4; ++i) {
+          if (pb + i < p.xnp) {
+            f32x4 v = t[i];
+#pragma unroll
+            for (int q = 0; q < 4; ++q) {
+              if (XFK == LXF_FILM) { const float h = v[q] * (1.f + a[i][q]) + c[i][q]; v[q] = fmaxf(h, h * p.slope); }
+              else if (XFK == LXF_MASK_LRELU) v[q] = a[i][q] > 0.f ? v[q] : v[q] * p.slope;
+              else v[q] = v[q] * (1.f - a[i][q] * a[i][q]);
+              v[q] *= p.in_scale;
+            }
+            if (xw.active) *reinterpret_cast<f32x4*>(dst) = v;
+            dst += xw.lstep;
+          }
+        }
       }
     } else {   // edge tile: per-element padding logic
       for (int r = wave; r < p.Cc; r += 4) {
@@ -189,17 +252,20 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 2 : (M_REP * N_REP >= 8
         for (int i = lane; i < p.span; i += 64) row[i] = rv ? lean_fetch<(XFK == LXF_COND ? LXF_ACT : XFK)>(p, b, c0 + r, q0 + i) : 0.f;
       }
     }
-    tile_commit<WVV>(wr, nullptr, nullptr, wxf, ws, p.WS, mvalid, MT, jc, 0, tid);
+    walk_commit_w<WVP>(wr, ww, p.wnp, ws);
+    PROF(2)
     __syncthreads();
+    PROF(3)
     if (c0 + p.Cc < p.Cin) {
       if (xpipe) x_issue(c0 + p.Cc);
       w_issue(c0 + p.Cc);
     }
+    PROF(4)
 
     // MFMA: D[t][co] += X'[t][k] * W[k][co]; one step = 4 channels of one tap. Fragments of step s+1 are
     // read from LDS into the other register set before the MFMAs of step s issue (software pipelining);
     // the (tap, channel-group) walk is kept in scalar registers so a step costs 1 + M_REP vector adds.
-    const int csteps = p.Cc >> 2;
+    const int csteps = cvalid >> 2;                        // rows past cvalid are never read (Cin % 4 == 0)
     const int nsteps = p.K * csteps;
     const float* w_lane = ws + (wrow0 + ln) * p.WS + kq * p.K;
     const float* x_lane = xs + kq * p.XS + wcol0 + ln + p.i0;
@@ -268,6 +334,7 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 2 : (M_REP * N_REP >= 8
         }
       }
     }
+    PROF(5)
   }
 
   // ---- epilogue: lane owns channel co = .. + ln and time steps t0 .. t0+3 (t0 % 4 == 0, T % 4 == 0)
@@ -368,9 +435,25 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 2 : (M_REP * N_REP >= 8
       *reinterpret_cast<f32x4*>(p.y + (long)b * p.y_bs + oi) = v;
     }
   }
+  PROF(6)
+  PROF_END
 }
 
 // ------------------------------------------------------------------------------------------ host
+#ifdef LEAN_PROF
+}  // namespace tdvc
+extern "C" int tdvc_debug_lean_prof(void* buf) {
+  return (int)hipMemcpyToSymbol(HIP_SYMBOL(tdvc::g_lean_prof), &buf, sizeof(buf));
+}
+namespace tdvc {
+#endif
+// Row-walk geometry of a tile of `rows` rows x `nvec` float4: rows per pass and number of passes (conv_common.h RowWalk).
+static inline void walk_geometry(int rows, int nvec, int* rp, int* np) {
+  *rp = nvec <= 256 ? 256 / nvec : 0;
+  if (*rp > rows) *rp = rows;
+  *np = *rp ? (rows + *rp - 1) / *rp : 1 << 20;
+}
+
 template <typename K> static inline void lean_big_lds(K k) {
   hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
 }
@@ -382,7 +465,7 @@ static hipError_t lean_launch3(const LeanP& p, int B, hipStream_t st) {
   static bool once = false;
   if (!once) { lean_big_lds(k); once = true; }
   dim3 grid((p.T + NT - 1) / NT, (p.Cout + MT - 1) / MT, B);
-  const size_t lds = (size_t)(p.Cc * p.XS + MT * p.WS) * sizeof(float);
+  const size_t lds = (size_t)(p.xnp * p.xrp * p.XS + p.wnp * p.wrp * p.WS) * sizeof(float);
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
   return hipGetLastError();
 }
@@ -411,12 +494,15 @@ hipError_t launch_conv_lean_cond(LeanP p, int B, hipStream_t st) {
   p.span = ((NT + (p.K - 1) * p.d - p.pad - lo) + 3) / 4 * 4;
   p.XS = ((p.span + 31) / 32) * 32 + 16;
   p.ES = ((p.span + 15) / 16) * 16 + 4;
-  const int wvv = MT >= 48 ? 10 : 6;
   int Cc = 32;
-  if ((size_t)(Cc * p.XS + MT * (p.K * Cc + 2) + p.Cv * p.ES + Cc * 25) * 4 > 80 * 1024 || (long)MT * p.K * Cc > wvv * 1024) Cc = 16;
-  p.Cc = Cc;
-  p.WS = p.K * Cc + 2;
-  const size_t lds = (size_t)(Cc * p.XS + MT * p.WS + p.Cv * p.ES + Cc * 25) * sizeof(float);
+  auto geom = [&](int cc) {
+    p.Cc = cc; p.WS = p.K * cc + 2;
+    p.xrp = cc; p.xnp = 1;                               // the input tile is computed, not loaded: Cc rows
+    walk_geometry(MT, p.K * cc / 4, &p.wrp, &p.wnp);
+    return (size_t)(cc * p.XS + p.wnp * p.wrp * p.WS + p.Cv * p.ES + cc * 25) * sizeof(float);
+  };
+  size_t lds = geom(Cc);
+  if (lds > 80 * 1024 || p.wnp > (MT >= 48 ? 10 : 6)) lds = geom(Cc = 16);
   dim3 grid((p.T + NT - 1) / NT, (p.Cout + MT - 1) / MT, B);
   if (MT == 32) {
     auto k = conv_lean_kernel<2, 4, 1, 4, LXF_COND, EPI_FWD>;
@@ -458,18 +544,17 @@ hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st) {
   p.lo = lo; p.i0 = first - lo;
   p.span = ((NT + hi - lo) + 3) / 4 * 4;
   p.XS = ((p.span + 31) / 32) * 32 + 16;
-  const int xv = (xfk == LXF_ACT) ? (MT >= 48 ? 8 : 6) : 4;
-  const int wvv = MT >= 48 ? 10 : (MT >= 32 ? 6 : 3);
-  int Cc = 4;
-  while (true) {
-    const int next = Cc + 4;
-    if (next > 32 || next > ((p.Cin + 3) / 4) * 4) break;
-    const size_t lds = (size_t)(next * p.XS + MT * (p.K * next + 2)) * 4;
-    if (lds > 64 * 1024) break;
-    if ((xfk == LXF_ACT && (long)next * (p.span >> 2) > xv * 256) || (long)MT * p.K * next > wvv * 1024) break;
-    Cc = next;
+  const int xvp = MT >= 32 ? 12 : 6, wvp = MT >= 48 ? 10 : (MT >= 32 ? 6 : 4);   // = the kernel's XVP / WVP
+  int Cc = 0;
+  for (int cc = 4; cc <= 32 && cc <= ((p.Cin + 3) / 4) * 4; cc += 4) {
+    int xrp, xnp, wrp, wnp;
+    walk_geometry(cc, p.span / 4, &xrp, &xnp);
+    walk_geometry(MT, p.K * cc / 4, &wrp, &wnp);
+    const size_t lds = (size_t)(xnp * xrp * p.XS + wnp * wrp * (p.K * cc + 2)) * 4;
+    if (lds > 64 * 1024 || wnp > wvp || (xfk == LXF_ACT && xnp > xvp)) continue;
+    Cc = cc; p.xrp = xrp; p.xnp = xnp; p.wrp = wrp; p.wnp = wnp;
   }
-  if ((long)MT * p.K * Cc > wvv * 1024) return hipErrorNotSupported;      // weight tile would not fit the register prefetch
+  if (!Cc) return hipErrorNotSupported;                  // weight tile would not fit the register prefetch
   p.Cc = Cc;
   p.WS = p.K * Cc + 2;
   switch (cfg) {

@@ -10,7 +10,7 @@ sub = rows[lo:hi]
 cat, cnt, shapes = collections.Counter(), collections.Counter(), collections.defaultdict(collections.Counter)
 def c(n):
     m = re.search(r'conv_lean_kernel<(\d+), (\d+), (\d+), (\d+), (\d+), (\d+)', n)
-    if m: return 'lean M%sN%s W%sx%s' % m.group(1, 2, 3, 4)
+    if m: return 'lean M%sN%s W%sx%s xf%s epi%s' % m.group(1, 2, 3, 4, 5, 6)
     for key in ('wgrad_tile', 'wgrad_lean', 'conv_wgrad_kernel', 'conv_gemm_kernel', 'scalar', 'slab_reduce'):
         if key in n: return key
     if 'at::native' in n: return 'aten'
@@ -20,7 +20,7 @@ for r in sub:
     k = c(r['Kernel_Name']); cat[k] += dur; cnt[k] += 1
     shapes[k][(r['Grid_Size_X'], r['Grid_Size_Y'], r['Grid_Size_Z'])] += dur
 tot = sum(cat.values())
-for k, v in cat.most_common(18):
+for k, v in cat.most_common(40):
     print(f'{v / 1e6 / nsteps:8.2f} ms/step {100 * v / tot:5.1f}%  n/step={cnt[k] / nsteps:6.0f}  {k}')
     for g, dd in shapes[k].most_common(4): print(f'            grid={g}: {dd / 1e6 / nsteps:6.2f} ms/step')
 print('kernel total/step', tot / 1e6 / nsteps, 'wall span/step', (int(sub[-1]['End_Timestamp']) - int(sub[0]['Start_Timestamp'])) / 1e6 / nsteps)
