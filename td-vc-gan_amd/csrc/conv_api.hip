@@ -3,6 +3,7 @@
 #include "../../include/tdvc.h"
 #include "conv_common.h"
 #include "conv_lean.h"
+#include "conv_wgrad_lean.h"
 #include "api_util.h"
 
 namespace tdvc {
@@ -18,18 +19,7 @@ hipError_t launch_bias_grad(const Opnd&, int, int, int, float*, hipStream_t);
 
 namespace tdvc {
 
-struct WgLeanP {
-  Opnd a; Opnd x;
-  int R, Cin, N, pad, K, reflect, B;
-  int lo, span, i0;
-  int ntiles;
-  int tpb, ngroups;
-  float* slab; long slab_stride;
-  int vec;
-  long bias_off;
-};
-bool wgrad_lean_supported(int J, int D);
-hipError_t launch_conv_wgrad_lean(WgLeanP p, int B, int J, int D, hipStream_t st);
+
 }  // namespace tdvc
 
 using namespace tdvc;

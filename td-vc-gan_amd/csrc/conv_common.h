@@ -177,7 +177,14 @@ typedef __amdgpu_buffer_rsrc_t srd_t;
 typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
 
 __device__ __forceinline__ srd_t make_srd(const float* base, int bytes) {   // wave-uniform inputs only
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<float*>(base), 0, bytes > 0 ? bytes : 0, 0x00020000);
+  // readfirstlane on the descriptor inputs makes the uniformity provable: without it a base that went through the
+  // vector ALU (integer division, 64-bit multiply) puts every load behind a waterfall loop (cdna_hip_programming.md T20)
+  const uintptr_t a = reinterpret_cast<uintptr_t>(base);
+  const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)(a & 0xffffffffu));
+  const unsigned hi = __builtin_amdgcn_readfirstlane((unsigned)(a >> 32));
+  const int nb = __builtin_amdgcn_readfirstlane(bytes > 0 ? bytes : 0);
+  float* ub = reinterpret_cast<float*>(((uintptr_t)hi << 32) | lo);
+  return __builtin_amdgcn_make_buffer_rsrc(ub, 0, nb, 0x00020000);
 }
 __device__ __forceinline__ f32x4_t buf_load4(srd_t rs, int voff) {
   return __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
@@ -302,5 +309,24 @@ __device__ __forceinline__ void tile_commit_s(const RegS<NS>& t, const RegS<NS>*
     dst[r * XS + (e - r * span)] = v * xf.scale;
   }
 }
+
+// Phase-cycle instrumentation for tools/lean_phase_prof.py (diagnostic build only: `make prof`; no stamp executes in the product .so).
+#ifdef LEAN_PROF
+// each instrumented translation unit defines its own buffer pointer (no relocatable device code): PROF_DEFINE(setter)
+#define PROF_DEFINE(setter) namespace tdvc { static __device__ unsigned long long* g_lean_prof = nullptr; } \
+  extern "C" int setter(void* buf) { return (int)hipMemcpyToSymbol(HIP_SYMBOL(tdvc::g_lean_prof), &buf, sizeof(buf)); }
+#define PROF_DECL unsigned long long pt_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pl_ = __builtin_amdgcn_s_memtime(); const unsigned long long pr0_ = __builtin_amdgcn_s_memrealtime();
+#define PROF(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pt_[i] += n_ - pl_; pl_ = n_; }
+#define PROF_WAITV() __builtin_amdgcn_s_waitcnt(0x0f70);   /* vmcnt(0) only (gfx9 encoding: lgkmcnt/expcnt fields left at max) */
+#define PROF_END { pt_[7] = __builtin_amdgcn_s_memrealtime() - pr0_; if (g_lean_prof && threadIdx.x == 0) { \
+    unsigned long long* o_ = g_lean_prof + 10 * ((unsigned long long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x); \
+    for (int i_ = 0; i_ < 10; ++i_) o_[i_] = pt_[i_]; } }
+#else
+#define PROF_DEFINE(setter)
+#define PROF_DECL
+#define PROF(i)
+#define PROF_WAITV()
+#define PROF_END
+#endif
 
 }  // namespace tdvc

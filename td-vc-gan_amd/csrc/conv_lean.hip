@@ -12,6 +12,8 @@
 #include "conv_common.h"
 #include "conv_lean.h"
 
+PROF_DEFINE(tdvc_debug_lean_prof)
+
 namespace tdvc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -23,21 +25,6 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 // the 136-channel intermediate is written once (for the backward pass) and never read back by the forward.
 
 
-// Phase-cycle instrumentation for tools/lean_phase_prof.py (diagnostic build only: `make prof`; no stamp executes in the product .so).
-#ifdef LEAN_PROF
-__device__ unsigned long long* g_lean_prof = nullptr;
-#define PROF_DECL unsigned long long pt_[10] = {0, 0, 0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pl_ = __builtin_amdgcn_s_memtime(); const unsigned long long pr0_ = __builtin_amdgcn_s_memrealtime();
-#define PROF(i) { const unsigned long long n_ = __builtin_amdgcn_s_memtime(); pt_[i] += n_ - pl_; pl_ = n_; }
-#define PROF_WAITV() __builtin_amdgcn_s_waitcnt(0x0f70);   /* vmcnt(0) only (gfx9 encoding: lgkmcnt/expcnt fields left at max) */
-#define PROF_END { pt_[7] = __builtin_amdgcn_s_memrealtime() - pr0_; if (g_lean_prof && threadIdx.x == 0) { \
-    unsigned long long* o_ = g_lean_prof + 10 * ((unsigned long long)(blockIdx.z * gridDim.y + blockIdx.y) * gridDim.x + blockIdx.x); \
-    for (int i_ = 0; i_ < 10; ++i_) o_[i_] = pt_[i_]; } }
-#else
-#define PROF_DECL
-#define PROF(i)
-#define PROF_WAITV()
-#define PROF_END
-#endif
 
 template <int XFK>
 __device__ __forceinline__ float lean_xform(const LeanP& p, float v, int b, int c, int q) {
@@ -440,13 +427,6 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 12 ? 2 : ((M_REP * N_REP >= 
 }
 
 // ------------------------------------------------------------------------------------------ host
-#ifdef LEAN_PROF
-}  // namespace tdvc
-extern "C" int tdvc_debug_lean_prof(void* buf) {
-  return (int)hipMemcpyToSymbol(HIP_SYMBOL(tdvc::g_lean_prof), &buf, sizeof(buf));
-}
-namespace tdvc {
-#endif
 // Row-walk geometry of a tile of `rows` rows x `nvec` float4: rows per pass and number of passes (conv_common.h RowWalk).
 static inline void walk_geometry(int rows, int nvec, int* rp, int* np) {
   *rp = nvec <= 256 ? 256 / nvec : 0;

@@ -7,22 +7,12 @@
 // address in the MFMA loop is base + immediate: one vector add per step. Fragments of step s+1 are fetched
 // before the MFMAs of step s issue.
 #include "conv_common.h"
+#include "conv_wgrad_lean.h"
 
 namespace tdvc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-struct WgLeanP {
-  Opnd a;            // dy-like rows [B][R][N]
-  Opnd x;            // x-like rows  [B][Cin][T]
-  int R, Cin, N, pad, K, reflect, B;
-  int lo, span, i0;
-  int ntiles;        // 256-step chunks per sample
-  int tpb, ngroups;  // chunks per block, chunk groups per sample (slabs = B * ngroups)
-  float* slab; long slab_stride;
-  int vec;
-  long bias_off;     // >= 0: per-slab bias partial sums (row sums of the staged dy' tile) at slab[bias_off + row]
-};
 
 constexpr int WG_NTC = 256;
 constexpr int WG_AS = 258;     // 2 (mod 32)
@@ -370,6 +360,10 @@ static hipError_t wg_launch_jd(WgLeanP& p, int B, hipStream_t st) {
   p.B = B;
   if (p.R <= 16 || p.Cin <= 16) return wg_launch<1, 1, J, D>(p, B, st);
   if (J == 15) return hipErrorNotSupported;      // 15-tap layers on the path are narrow (D layer 0: 1 -> 16)
+  {   // aligned rows with plain / FiLM prologues: the pipelined kernel (conv_wgrad_pipe.hip)
+    const hipError_t e = launch_conv_wgrad_pipe(p, J, D, st);
+    if (e != hipErrorNotSupported) return e;
+  }
   // wide layers: 64-step chunks, register tile per wave
   p.span = ((WT_NTC + (J - 1) * D - p.pad - p.lo) + 3) / 4 * 4;
   if (p.R <= 32) {
@@ -384,13 +378,18 @@ static hipError_t wg_launch_jd(WgLeanP& p, int B, hipStream_t st) {
 void wgrad_lean_plan(int R, int Cin, int N, int K, int B, int* ntiles, int* tpb, int* ngroups) {
   const bool narrow = (R <= 16 || Cin <= 16);
   const int ntc = narrow ? WG_NTC : WT_NTC;
-  const int mt = narrow ? 16 : (R <= 32 ? 32 : 64), ctw = narrow ? 16 : (K <= 3 ? 64 : 32);
+  const int mt = narrow ? 16 : ((R <= 32 || K >= 11) ? 32 : 64), ctw = narrow ? 16 : (K <= 3 ? 64 : 32);
   *ntiles = (N + ntc - 1) / ntc;
   const long tiles = (long)((R + mt - 1) / mt) * ((Cin + ctw - 1) / ctw);
   const long blocks = (long)B * (*ntiles) * tiles;
-  // narrow: ~4 blocks per CU (latency-bound, no intra-block pipeline); wide: ~2 per CU, the register-tile kernel
-  // prefetches across chunks, and fewer, longer blocks mean fewer partial slabs to write and fold
-  int t = (int)(blocks / (narrow ? 1024 : 512));
+  // narrow: ~4 blocks per CU (latency-bound, no intra-block pipeline); wide: the register-tile kernels run 2 blocks
+  // per CU and walk their chunks in a software pipeline, so the grid is sized to ONE resident wave of blocks
+  // (<= 512 on 256 CUs): a 513th block would run alone after the others and double the kernel time
+  int t = (int)(blocks / 1024);
+  if (!narrow) {
+    const long groups = tiles >= 512 ? 1 : 512 / tiles;
+    t = (int)(((long)B * (*ntiles) + groups - 1) / groups);
+  }
   if (t < 1) t = 1;
   if (narrow) {                                  // groups per sample
     if (t > *ntiles) t = *ntiles;

@@ -212,4 +212,6 @@ def test_graph_replay_matches_eager(dev):
     for k, v in res['eager'][0].items():
         # not bitwise: bias / slab folds use float atomics whose order differs from launch to launch
         assert abs(res['graph'][0][k] - v) <= TOL * (abs(v) + 1e-6), (k, res['graph'][0][k], v)
-    assert rel_l2(res['graph'][1], res['eager'][1]) < 1e-4 and rel_l2(res['graph'][2], res['eager'][2]) < 1e-4
+    # parameters after 4 AdamW steps: early Adam updates are ~lr*sign(g), so last-bit gradient differences (atomics)
+    # on near-zero gradient elements move single parameters by 2*lr
+    assert rel_l2(res['graph'][1], res['eager'][1]) < 5e-4 and rel_l2(res['graph'][2], res['eager'][2]) < 5e-4

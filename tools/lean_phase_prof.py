@@ -17,6 +17,7 @@ pkg = importlib.import_module('td-vc-gan_amd')
 ops, arena, L = pkg.ops, pkg.arena, pkg._lib
 L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), 'libtdvc_hip_prof.so')
 L.SIGNATURES['tdvc_debug_lean_prof'] = (C.c_int, [C.c_void_p])
+L.SIGNATURES['tdvc_debug_wgrad_prof'] = (C.c_int, [C.c_void_p])
 
 SHAPES = {  # name: (cin, cout, k, dil, T, reflect, pre)
     'c16k3': (16, 16, 3, 1, 16000, True, 1), 'c16k11d5': (16, 16, 11, 5, 16000, True, 1), 'c16k1': (16, 16, 1, 1, 16000, False, 1),
@@ -54,19 +55,21 @@ def main():
         fns = {
             'fwd': lambda: ops.conv_fwd_raw(spec, x, xf, out=y),
             'dgrad': lambda: ops.conv_dgrad_raw(spec, dy, ops._xf(), T, L.DG_MASK_LRELU if pre else L.DG_PLAIN, x_in=x if pre else None, out=dx),
+            'wgrad': lambda: ops.conv_wgrad_raw(spec, x, xf, dy, ops._xf()),
         }
         for which in a.which.split(','):
             f = fns[which]
-            lib.tdvc_debug_lean_prof(None)
+            setp = lib.tdvc_debug_wgrad_prof if which == 'wgrad' else lib.tdvc_debug_lean_prof
+            setp(None)
             for _ in range(20):
                 f()
             buf.zero_()
-            lib.tdvc_debug_lean_prof(buf.data_ptr())
+            setp(buf.data_ptr())
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             torch.cuda.synchronize(); e0.record()
             f()
             e1.record(); torch.cuda.synchronize()
-            lib.tdvc_debug_lean_prof(None)
+            setp(None)
             r = buf.view(-1, 10).cpu()
             r = r[r[:, 7] > 0].double()
             tot = r[:, :7].sum(1) + r[:, 8]
