@@ -123,6 +123,23 @@ typedef struct {
 } tdvc_film_cond_args;
 int tdvc_film_cond_fwd(const tdvc_film_cond_args* a, void* stream);
 
+/* Backward of cond_var.0 in the split formulation, everything that consumes d_cv0 = dL/d(cond_var.0 output) in one pass:
+ * dexc (input-grad wrt the excitation), the excitation window of dW (accumulated into dw0, module layout
+ * [n_cond][n_cond][3]) and dk3 (adjoint of the 3-valued bias: first step, interior sum, last step). Replaces the
+ * conv_wgrad + conv_dgrad + edge_sum3 calls on the same tensor. Needs T % 4 == 0, n_var == 8, n_cond <= 144. */
+typedef struct {
+  int32_t B, T, n_cond, n_var;
+  const float* dcv; int64_t dcv_bs;     /* [B][n_cond][T] */
+  const float* exc; int64_t exc_bs;     /* [B][n_var][T] */
+  const float* w0;                      /* cond_var.0 effective weight [n_cond][n_cond][3] */
+  float* dexc; int64_t dexc_bs;         /* [B][n_var][T], optional */
+  float* dk3;                           /* [B][n_cond][3] */
+  float* dw0;                           /* weight-gradient accumulator of cond_var.0, optional */
+  void* workspace; size_t workspace_bytes;   /* tdvc_film_cond0_bwd_workspace() bytes when dw0 is given */
+} tdvc_film_cond0_bwd_args;
+size_t tdvc_film_cond0_bwd_workspace(int32_t B, int32_t T, int32_t n_cond, int32_t n_var);
+int tdvc_film_cond0_bwd(const tdvc_film_cond0_bwd_args* a, void* stream);
+
 /* Multi-tensor weight norm (old-style nn.utils.weight_norm, dim=0; model/generator.py:14,
  * util/__init__.py:16-20, model/discriminator.py:11): w[row] = g[row] * v[row] / ||v[row]||, one wave per
  * dim-0 slice, every weight-normed tensor of a model in ONE launch. `params` is the model's flat parameter

@@ -39,6 +39,13 @@ class FilmCondArgs(C.Structure):
                 ('gb', C.c_void_p), ('gb_bs', C.c_int64), ('slope', C.c_float)]
 
 
+class FilmCond0BwdArgs(C.Structure):
+    _fields_ = [('B', C.c_int32), ('T', C.c_int32), ('n_cond', C.c_int32), ('n_var', C.c_int32),
+                ('dcv', C.c_void_p), ('dcv_bs', C.c_int64), ('exc', C.c_void_p), ('exc_bs', C.c_int64), ('w0', C.c_void_p),
+                ('dexc', C.c_void_p), ('dexc_bs', C.c_int64), ('dk3', C.c_void_p), ('dw0', C.c_void_p),
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
+
+
 class ConvDgradArgs(C.Structure):
     _fields_ = [('dy', C.c_void_p), ('dy_bs', C.c_int64), ('dy_xf', Xform), ('w', C.c_void_p), ('wt', C.c_void_p),
                 ('epilogue', C.c_int32), ('x_in', C.c_void_p), ('x_in_bs', C.c_int64), ('slope', C.c_float),
@@ -66,6 +73,8 @@ SIGNATURES = {
     'tdvc_conv_wgrad': (_i, [C.POINTER(ConvDesc), C.POINTER(ConvWgradArgs), _vp]),
     'tdvc_conv_wgrad_workspace': (C.c_size_t, [C.POINTER(ConvDesc)]),
     'tdvc_film_cond_fwd': (_i, [C.POINTER(FilmCondArgs), _vp]),
+    'tdvc_film_cond0_bwd': (_i, [C.POINTER(FilmCond0BwdArgs), _vp]),
+    'tdvc_film_cond0_bwd_workspace': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     'tdvc_set_force_generic': (None, [_i]),
     'tdvc_weight_norm_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'tdvc_weight_norm_fwd_t': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),

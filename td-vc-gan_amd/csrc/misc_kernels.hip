@@ -322,7 +322,7 @@ __global__ __launch_bounds__(256) void log_l1_bwd_kernel(const float* a, const f
 }
 
 // ------------------------------------------------------------------------------ contrastive InfoNCE
-// One block per (direction, sample): stages Z = anchor-side embedding [C][T] in LDS, loops over t.
+// One block per (direction, sample, time slice): stages Z = anchor-side embedding [C][T] in LDS, loops over its t.
 // logits[k] = cos(A[:,t], target_k), target_0 = P[:,t] (other side), target_{1+n} = Z[:, neg(t,n)] (detached).
 // dA / dP accumulate with atomics (each tensor is anchor in one direction and positive in the other).
 __global__ __launch_bounds__(128) void contrastive_kernel(const float* X, const float* Y, const int32_t* idx_x, const int32_t* idx_y,
@@ -350,7 +350,7 @@ __global__ __launch_bounds__(128) void contrastive_kernel(const float* X, const 
   }
   __syncthreads();
   float loss_acc = 0.f;
-  for (int t = 0; t < T; ++t) {
+  for (int t = blockIdx.z; t < T; t += gridDim.z) {     // time steps are independent given Z
     float ps = 0.f;
     for (int c = tid; c < C; c += 128) { float v = P[c * T + t]; ps += v * v; }
     ps = wave_sum(ps);
@@ -556,6 +556,7 @@ extern "C" int tdvc_contrastive_fwd_bwd(const float* X, const float* Y, const in
   static bool once = false;
   if (!once) { hipFuncSetAttribute(reinterpret_cast<const void*>(contrastive_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
   const float coef = weight / (2.f * (float)B * (float)T);
-  hipLaunchKernelGGL(contrastive_kernel, dim3(2, B), dim3(128), lds, (hipStream_t)stream, X, Y, idx_x, idx_y, C, T, N, coef, loss_out, dX, dY);
+  const int tsplit = T < 16 ? T : 16;            // 2 * B * 16 blocks instead of 2 * B serial walks over T
+  hipLaunchKernelGGL(contrastive_kernel, dim3(2, B, tsplit), dim3(128), lds, (hipStream_t)stream, X, Y, idx_x, idx_y, C, T, N, coef, loss_out, dX, dY);
   TDVC_CHECK_LAUNCH(); return TDVC_OK;
 }

@@ -260,10 +260,22 @@ class FilmCondFn(Function):
         B, nc, T = cv0.shape
         conv_wgrad_raw(ctx.s2, cv0, _xf(L.XF_LRELU), dgb, _xf())
         dcv = conv_dgrad_raw(ctx.s2, dgb, _xf(), T, L.DG_MASK_LRELU, x_in=cv0)
-        conv_wgrad_raw(ctx.sv, exc, _xf(), dcv, _xf())
-        dexc = conv_dgrad_raw(ctx.sv, dcv, _xf(), T, L.DG_PLAIN) if ctx.needs_input_grad[0] else None
+        # everything that consumes d_cv0 in one pass over it: dexc, the excitation window of cond_var.0's weight-grad, dk3
+        lib = L.lib()
+        sv = ctx.sv.slot
+        nv = exc.shape[1]
+        want_w = sv.trainable and (sv.arena is None or sv.arena.wgrad_enabled)
+        dexc = torch.empty_like(exc) if ctx.needs_input_grad[0] else None
         dk3 = torch.empty((B, nc, 3), dtype=torch.float32, device=dgb.device)
-        L.check(L.lib().tdvc_edge_sum3(dcv.data_ptr(), dk3.data_ptr(), B, nc, T, _stream(dgb)))
+        nbytes = lib.tdvc_film_cond0_bwd_workspace(B, T, nc, nv) if want_w else 0
+        ws = workspace(dgb.device, nbytes) if nbytes else None
+        a = L.FilmCond0BwdArgs(B, T, nc, nv, dcv.data_ptr(), _bs(dcv), exc.data_ptr(), _bs(exc), sv.w,
+                               dexc.data_ptr() if dexc is not None else None, _bs(dexc) if dexc is not None else 0,
+                               dk3.data_ptr(), sv.dw if want_w else None,
+                               ws.data_ptr() if ws is not None else None, ws.numel() * ws.element_size() if ws is not None else 0)
+        L.check(lib.tdvc_film_cond0_bwd(C.byref(a), _stream(dgb)))
+        if want_w and sv.arena is not None:
+            sv.arena.queue_finish()
         return dexc, dk3, None, None, None
 
 
