@@ -26,7 +26,7 @@ import torch.distributed as dist  # noqa: E402
 SR = 16000
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3    # fp32-input MFMA = fp32 vector peak
-PMC_TRAFFIC_BYTES = 47.1e6   # (2*FETCH_SIZE + WRITE_SIZE) KiB per launch, profiles/r01_pmc_traffic.txt (algorithmic: 32.8e6)
+PMC_TRAFFIC_BYTES = None     # filled from profiles/r01_pmc_traffic.txt below ((2*FETCH_SIZE + WRITE_SIZE) KiB per launch)
 
 
 def time_conv_kernel(pkg, dev, B, cin, cout, k, dil, T, iters=50):
@@ -54,6 +54,18 @@ def time_conv_kernel(pkg, dev, B, cin, cout, k, dil, T, iters=50):
     alg_bytes = 4.0 * B * (cin * T + cout * T) + 4.0 * (cout * cin * k + cout)
     flops = 2.0 * B * T * cout * cin * k
     return ms, alg_bytes, flops
+
+
+def pmc_traffic_bytes():
+    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE,
+    gfx950 correction per MI355X_MICROARCH.md); None when the profile file is absent."""
+    try:
+        for line in open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.txt')):
+            if line.startswith('ROOFLINE_KERNEL_HBM_BYTES_PER_LAUNCH'):
+                return float(line.split('=')[1])
+    except OSError:
+        pass
+    return None
 
 
 def usable_cores():
@@ -165,14 +177,18 @@ def main():
         # roofline of the dilated Conv1d kernel the north star names (16->16, k=3, T=16000: the HBM-bound end).
         # traffic: HBM bytes per launch from the committed rocprofv3 PMC pass (profiles/, FETCH_SIZE doubled per
         # MI355X_MICROARCH.md) — not re-measured live (needs the profiler).
-        ms, alg_bytes, flops = time_conv_kernel(pkg, dev, B, 16, 16, 3, 1, T)
-        roof = dict(kernel='conv_lean_kernel<1,4,1,4,ACT,FWD> dilated Conv1d 16->16 k3 d1 T=16000 B=16 fwd (fused LeakyReLU+bias)',
+        # Launch shape = the step's: every trunk conv runs on 2*B samples (decoder: [target; identity] conditionings,
+        # encoder: [real; corrupted], discriminator: [real; fake]), one launch per layer.
+        BL = 2 * B
+        ms, alg_bytes, flops = time_conv_kernel(pkg, dev, BL, 16, 16, 3, 1, T)
+        roof = dict(kernel=f'conv_lean_kernel<1,4,1,4,ACT,FWD> dilated Conv1d 16->16 k3 d1 T=16000 B={BL} fwd (fused LeakyReLU+bias)',
                     bound='hbm', achieved=alg_bytes / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
-                    frac=alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=PMC_TRAFFIC_BYTES, ms_per_launch=ms,
+                    frac=alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=pmc_traffic_bytes(), ms_per_launch=ms,
                     algorithmic_bytes=alg_bytes)
-        # the FLOP-dominant kernel class of the step: FiLM conditioning conv 136 -> 2C, k3 (here C=64, T=4000)
-        ms2, _, fl2 = time_conv_kernel(pkg, dev, B, 136, 128, 3, 1, 4000)
-        roof['mfma_kernel'] = dict(kernel='conv_lean_kernel<4,4,1,4,ACT,FWD> FiLM cond_var.2 136->128 k3 T=4000 B=16 fwd', bound='mfma',
+        # the FLOP-dominant kernel class of the step: FiLM conditioning conv 136 -> 2C, k3 (here C=64, T=4000); the fused
+        # conditioning forward and the cond_var.2 input-grad run the same tile / MFMA loop
+        ms2, _, fl2 = time_conv_kernel(pkg, dev, BL, 136, 128, 3, 1, 4000)
+        roof['mfma_kernel'] = dict(kernel=f'conv_lean_kernel<4,4,1,4,ACT,FWD> FiLM cond_var.2 136->128 k3 T=4000 B={BL} fwd', bound='mfma',
                                    achieved=fl2 / (ms2 * 1e-3) / 1e12, peak=MFMA_F32_PEAK_TF, unit='TFLOP/s',
                                    frac=fl2 / (ms2 * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, ms_per_launch=ms2)
         out = dict(metric='audio-seconds/sec (G+D train step, stage-1)', value=value, unit='audio-seconds/sec', n_gpus=world,

@@ -162,3 +162,47 @@ def test_film_block(cfg, dev):
     if with_acc:
         errs['dacc'] = rel_l2(accd.grad, accr.grad)
     assert max(errs.values()) < TOL, errs
+
+
+@pytest.mark.parametrize('cfg', [(16, 2048, 2), (64, 600, 3), (128, 260, 2), (32, 64, 2)], ids=['C16_T2048', 'C64_T600', 'C128_T260', 'C32_T64'])
+def test_film_conditioning_fused(cfg, dev):
+    """tdvc_film_cond_fwd / tdvc_film_cond0_bwd (FiLM conditioning path of model/generator.py:86-92,103 in the split
+    formulation) against float64 autograd of the dense reference formulation
+        gb = cond_var.2(LeakyReLU(cond_var.0(cat([emb.repeat(T), exc]))))."""
+    ops, L, arena = _mods()
+    C, T, B = cfg
+    n_const, n_var = 128, 8
+    nc = n_const + n_var
+    torch.manual_seed(C + T)
+    emb = torch.randn(B, n_const, dtype=torch.float64)
+    exc = torch.randn(B, n_var, T, dtype=torch.float64)
+    w0 = torch.randn(nc, nc, 3, dtype=torch.float64) / (nc * 3) ** 0.5
+    b0 = torch.randn(nc, dtype=torch.float64) * 0.1
+    w2 = torch.randn(2 * C, nc, 3, dtype=torch.float64) / (nc * 3) ** 0.5
+    b2 = torch.randn(2 * C, dtype=torch.float64) * 0.1
+    embr, excr, w0r, b0r, w2r, b2r = [t.clone().requires_grad_(True) for t in (emb, exc, w0, b0, w2, b2)]
+    c = torch.cat([embr.unsqueeze(2).expand(B, n_const, T), excr], dim=1)
+    gbr = F.conv1d(F.leaky_relu(F.conv1d(c, w0r, b0r, padding=1), 0.2), w2r, b2r, padding=1)
+    cot = torch.randn_like(gbr)
+    (gbr * cot).sum().backward()
+
+    f = lambda t: t.float().to(dev).contiguous()
+    w0d, b0d, w2d, b2d = f(w0), f(b0), f(w2), f(b2)
+    dw0, db0, dw2, db2 = (torch.zeros_like(t) for t in (w0d, b0d, w2d, b2d))
+    w0t, w2t = w0d.permute(1, 0, 2).contiguous(), w2d.permute(1, 0, 2).contiguous()
+    spec_const = ops.ConvSpec(n_const, nc, 3, pad=1, w_cin=nc, w_cin_off=0)
+    spec_var = ops.ConvSpec(n_var, nc, 3, pad=1, w_cin=nc, w_cin_off=n_const)
+    spec2 = ops.ConvSpec(nc, 2 * C, 3, pad=1)
+    spec_const.slot = arena.ConvSlot(w0d.data_ptr(), b0d.data_ptr(), dw0.data_ptr(), db0.data_ptr(), True, None, w0t.data_ptr())
+    spec_var.slot = arena.ConvSlot(w0d.data_ptr(), 0, dw0.data_ptr(), 0, True, None, w0t.data_ptr())
+    spec2.slot = arena.ConvSlot(w2d.data_ptr(), b2d.data_ptr(), dw2.data_ptr(), db2.data_ptr(), True, None, w2t.data_ptr())
+    embd, excd = f(emb).requires_grad_(True), f(exc).requires_grad_(True)
+    emb3 = embd.unsqueeze(2).expand(B, n_const, 3).contiguous()      # the time-constant channels on a length-3 signal
+    k3 = ops.conv(emb3, spec_const)
+    gb = ops.film_cond(excd, k3, spec_var, spec2)
+    assert gb.shape == gbr.shape
+    gb.backward(f(cot))
+    torch.cuda.synchronize()
+    errs = dict(gb=rel_l2(gb, gbr), dexc=rel_l2(excd.grad, excr.grad), demb=rel_l2(embd.grad, embr.grad),
+                dw0=rel_l2(dw0, w0r.grad), db0=rel_l2(db0, b0r.grad), dw2=rel_l2(dw2, w2r.grad), db2=rel_l2(db2, b2r.grad))
+    assert max(errs.values()) < TOL, errs
