@@ -190,7 +190,7 @@ __device__ __forceinline__ f32x4_t buf_load4(srd_t rs, int voff) {
   return __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
 }
 
-struct RowWalk { int voff, loff, gstep, lstep; bool active; };
+struct RowWalk { int voff, loff, gstep, lstep, nk; bool active; };   // nk: valid components of the thread's float4 (rows with T % 4 != 0)
 
 // The pass-count guards are loop invariant; hidden from LICM they stay one s_cmp + branch each instead of a table
 // of precomputed lane masks that spills out of the SGPR file.
@@ -204,6 +204,7 @@ __device__ __forceinline__ RowWalk make_walk(int tid, int nvec, int rp, int rows
   const int q = q0 + 4 * vv;
   w.active = rsub < rp;
   w.voff = (w.active && q >= 0 && q < T) ? (rsub * rowstride + q) * 4 : 0x7f000000;
+  w.nk = T - q < 4 ? T - q : 4;
   w.loff = rsub * ls + 4 * vv;
   w.gstep = rp * rowstride * 4;
   w.lstep = rp * ls;
@@ -222,7 +223,7 @@ __device__ __forceinline__ void walk_issue(RegTile<NP>& t, srd_t rs, const RowWa
 // Input tile: LeakyReLU (slope 1 = identity) and scale on the way into LDS; rows are 16-byte aligned (ls % 4 == 0).
 // The activation is applied in place so that every LDS store has its own source registers (no store-to-store waits).
 template <int NP>
-__device__ __forceinline__ void walk_commit_act(RegTile<NP>& t, const RowWalk& w, int np, float* lds, float slope, float scale) {
+__device__ __forceinline__ void walk_commit_act(RegTile<NP>& t, const RowWalk& w, int np, float* lds, float slope, float scale, bool tail = false) {
   if (!w.active) return;
   const int base = w.loff;
 #pragma unroll
@@ -232,6 +233,10 @@ __device__ __forceinline__ void walk_commit_act(RegTile<NP>& t, const RowWalk& w
 #pragma unroll
       for (int q = 0; q < 4; ++q) { const float v = t.v[i][q]; o[q] = fmaxf(v, v * slope); }
       if (scale != 1.f) o *= scale;
+      if (tail) {                                        // rows with T % 4 != 0: the last float4 of a row runs into the next row
+#pragma unroll
+        for (int q = 1; q < 4; ++q) o[q] = q < w.nk ? o[q] : 0.f;
+      }
       *reinterpret_cast<f32x4_t*>(lds + base + i * w.lstep) = o;
       __builtin_amdgcn_sched_barrier(0);                 // one element at a time: keeps the temporaries to one float4
     }

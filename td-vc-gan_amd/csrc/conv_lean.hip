@@ -76,7 +76,10 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 12 ? 2 : ((M_REP * N_REP >= 
   // inside [0, T) or wholly outside (q0 % 4 == 0, T % 4 == 0), and outside columns carry an out-of-range offset, so
   // the buffer loads return the zero padding. Reflect padding (forward trunk convs, ACT prologue only) is patched
   // into the halo columns of the two end tiles after the commit.
-  const bool interior = (XFK != LXF_COND) && vec_ok && (XFK == LXF_ACT || !p.reflect);
+  // (the row walk only needs dword-aligned rows: sequences with T % 4 != 0 take it too, with the components past the row
+  //  end masked at the commit; only the dwordx4 epilogue needs 16-byte aligned rows)
+  const bool interior = (XFK != LXF_COND) && (XFK == LXF_ACT || !p.reflect);
+  const bool tail = (p.T & 3) != 0;
   const bool end_tile = q0 < 0 || q0 + p.span > p.T;
   const int jc = p.K * p.Cc;
   const float* xrow0 = p.x + (long)b * p.x_bs;
@@ -179,7 +182,7 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 12 ? 2 : ((M_REP * N_REP >= 
         }
       }
     } else if (xpipe) {
-      walk_commit_act<XVP>(xr, xw, p.xnp, xs, p.slope, p.in_scale);
+      walk_commit_act<XVP>(xr, xw, p.xnp, xs, p.slope, p.in_scale, tail);
       if (end_tile && p.reflect) {   // reflect halo of the first / last tile: columns with q < 0 or q >= T
         const int nl = q0 < 0 ? -q0 : 0;
         const int rfirst = p.T - q0;                       // first column index with q >= T
@@ -226,6 +229,7 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 12 ? 2 : ((M_REP * N_REP >= 
               else if (XFK == LXF_MASK_LRELU) v[q] = a[i][q] > 0.f ? v[q] : v[q] * p.slope;
               else v[q] = v[q] * (1.f - a[i][q] * a[i][q]);
               v[q] *= p.in_scale;
+              if (tail && q >= xw.nk) v[q] = 0.f;
             }
             if (xw.active) *reinterpret_cast<f32x4*>(dst) = v;
             dst += xw.lstep;
