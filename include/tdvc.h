@@ -203,6 +203,12 @@ int tdvc_log_l1_bwd(const float* a, const float* b, int64_t n, float floor_, flo
 /* Contrastive InfoNCE (util/losses.py:70-116): cosine logits, softmax, CE against class 0, both
  * directions, fused with its backward. idx_* [B][T][N] int32 are the negative positions (already skipping
  * self, util/losses.py:82-83). loss_out[0] += weight*CE; dX, dY += weight * dCE/d{X,Y} (zero them first). */
+/* Sine + noise excitation from a frame-level F0 track (util/__init__.py:22-50, f0_to_excitation): f0 [B][n_frames] in Hz
+ * (0 = unvoiced; the last frame is dropped as in the reference), output exc [B][(n_frames-1)*step]. The random draws are
+ * inputs: noise_v / noise_u [B][T] standard normal (voiced / unvoiced samples), start_phase [1] in radians (device pointer). */
+int tdvc_f0_to_excitation(const float* f0, const float* noise_v, const float* noise_u, const float* start_phase, float* exc,
+                          int B, int n_frames, int step, float sampling_rate, int linear, void* stream);
+
 int tdvc_contrastive_fwd_bwd(const float* X, const float* Y, const int32_t* idx_x, const int32_t* idx_y, int B, int C, int T, int N,
                              float weight, float* loss_out, float* dX, float* dY, void* stream);
 

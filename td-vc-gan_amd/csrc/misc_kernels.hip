@@ -405,6 +405,49 @@ __global__ __launch_bounds__(128) void contrastive_kernel(const float* X, const 
   if (tid == 0) atomicAdd(loss, loss_acc * coef);
 }
 
+
+// ------------------------------------------------------------------------------ sine + noise excitation from F0
+// util/__init__.py:22-50 (f0_to_excitation): omega = 2 pi f0 / sr per frame (last frame dropped), nearest-upsampled by
+// `step`, linearly interpolated (align_corners=False) where both neighbouring frames are voiced, cumulative phase,
+// 0.1 sin(phase + phi0) + 0.003 n_v; unvoiced samples (omega == 0) are 0.1/3 n_u. The random draws are inputs.
+// One block per sample: per-thread contiguous segment, block scan of the segment sums (double: 16000..71680 terms).
+__device__ __forceinline__ double exc_omega(const float* f0, int n, int t, int step, double k, int linear) {
+  const int fr = t / step;
+  const double wn = k * (double)f0[fr];
+  if (!linear) return wn;
+  double src = ((double)t + 0.5) / (double)step - 0.5;
+  if (src < 0.0) src = 0.0;
+  int i0 = (int)src; if (i0 > n - 1) i0 = n - 1;
+  const int i1 = i0 + 1 < n ? i0 + 1 : n - 1;
+  const double lam = src - (double)i0;
+  const double w0 = k * (double)f0[i0], w1 = k * (double)f0[i1];
+  return (w0 > 0.0 && w1 > 0.0) ? w0 * (1.0 - lam) + w1 * lam : wn;
+}
+
+__global__ __launch_bounds__(256) void f0_excitation_kernel(const float* f0, const float* noise_v, const float* noise_u, const float* phi0,
+                                                            float* exc, int nf1, int step, float sr, int linear) {
+  __shared__ double part[256];
+  const int b = blockIdx.x, tid = threadIdx.x;
+  const int n = nf1 - 1, T = n * step;
+  const float* f = f0 + (long)b * nf1;
+  const double k = 6.283185307179586 / (double)sr;
+  const int per = (T + 255) / 256;
+  const int t0 = tid * per, t1 = min(T, t0 + per);
+  double s = 0.0;
+  for (int t = t0; t < t1; ++t) s += exc_omega(f, n, t, step, k, linear);
+  part[tid] = s;
+  __syncthreads();
+  if (tid == 0) { double run = 0.0; for (int i = 0; i < 256; ++i) { const double v = part[i]; part[i] = run; run += v; } }
+  __syncthreads();
+  double ph = part[tid] + (double)phi0[0];
+  for (int t = t0; t < t1; ++t) {
+    const double w = exc_omega(f, n, t, step, k, linear);
+    ph += w;
+    const long i = (long)b * T + t;
+    exc[i] = w == 0.0 ? noise_u[i] * (0.1f / 3.0f) : 0.1f * (float)sin(ph) + noise_v[i] * 0.003f;
+  }
+}
+
 }  // namespace
 
 // ================================================================================================ C ABI
@@ -558,5 +601,14 @@ extern "C" int tdvc_contrastive_fwd_bwd(const float* X, const float* Y, const in
   const float coef = weight / (2.f * (float)B * (float)T);
   const int tsplit = T < 16 ? T : 16;            // 2 * B * 16 blocks instead of 2 * B serial walks over T
   hipLaunchKernelGGL(contrastive_kernel, dim3(2, B, tsplit), dim3(128), lds, (hipStream_t)stream, X, Y, idx_x, idx_y, C, T, N, coef, loss_out, dX, dY);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+
+extern "C" int tdvc_f0_to_excitation(const float* f0, const float* noise_v, const float* noise_u, const float* start_phase, float* exc,
+                                     int B, int n_frames, int step, float sampling_rate, int linear, void* stream) {
+  if (!f0 || !noise_v || !noise_u || !start_phase || !exc) return tdvc_fail(TDVC_EINVAL, "f0_to_excitation: null pointer");
+  if (B <= 0 || n_frames < 2 || step <= 0 || sampling_rate <= 0.f) return tdvc_fail(TDVC_EINVAL, "f0_to_excitation: bad shape");
+  hipLaunchKernelGGL(f0_excitation_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, f0, noise_v, noise_u, start_phase, exc, n_frames, step,
+                     sampling_rate, linear);
   TDVC_CHECK_LAUNCH(); return TDVC_OK;
 }

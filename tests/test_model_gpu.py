@@ -215,3 +215,18 @@ def test_graph_replay_matches_eager(dev):
     # parameters after 4 AdamW steps: early Adam updates are ~lr*sign(g), so last-bit gradient differences (atomics)
     # on near-zero gradient elements move single parameters by 2*lr
     assert rel_l2(res['graph'][1], res['eager'][1]) < 5e-4 and rel_l2(res['graph'][2], res['eager'][2]) < 5e-4
+
+
+def test_f0_to_excitation_device_vs_reference_golden(dev):
+    """tdvc_f0_to_excitation against the reference's own output with the same random draws."""
+    g = np.load(os.path.join(GOLDEN, 'f0_excitation.npz'))
+    U = pkg().util
+    t = lambda a: torch.from_numpy(a).to(dev)
+    exc = U.f0_to_excitation(t(g['f0']), int(g['step']), 16000, True, noise=(t(g['noise_v']), t(g['noise_u'])), start_phase=t(g['start_phase']))
+    torch.cuda.synchronize()
+    ref = torch.from_numpy(g['exc'])
+    assert exc.shape == ref.shape
+    assert float((exc.cpu() - ref).abs().max()) < 1e-4          # 1e-3 of the 0.1 sine amplitude (north star tolerance)
+    # default path: draws on the device, same statistics
+    exc2 = U.f0_to_excitation(t(g['f0']), int(g['step']))
+    assert exc2.shape == ref.shape and abs(float(exc2.std()) - float(ref.std())) < 0.1 * float(ref.std())

@@ -116,3 +116,22 @@ def test_full_iteration_vs_golden():
     log = st.run(bt, ix, iy)
     for k, v in gold['losses'][0].items():
         assert abs(log[k] - v) <= 1e-5 * (abs(v) + 1e-12), k
+
+
+def test_excitation_restatement_vs_reference_golden():
+    """synth.excitation_from_f0 (numpy restatement of util/__init__.py:22-50) against the output of the reference's own
+    f0_to_excitation with its three random draws replayed (tests/golden/f0_excitation.npz, oracle/make_golden_f0.py)."""
+    import importlib
+    import numpy as np
+    synth = importlib.import_module('td-vc-gan_amd.synth')
+    g = np.load(os.path.join(GOLDEN, 'f0_excitation.npz'))
+
+    class Replay:
+        k = 0
+        def uniform(self): return float(g['start_phase'][0]) / (2 * np.pi)
+        def randn(self, *shape):
+            self.k += 1
+            return (g['noise_v'] if self.k == 1 else g['noise_u']).astype(np.float64)
+    ours = synth.excitation_from_f0(g['f0'], Replay(), int(g['step']))
+    assert ours.shape == g['exc'].shape
+    assert float(np.abs(ours - g['exc']).max()) < 2e-5      # amplitude 0.1; the reference accumulates the phase in fp32
