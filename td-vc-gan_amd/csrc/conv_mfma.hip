@@ -503,11 +503,19 @@ static hipError_t launch_gemm_cfg(const GemmConvP& p, int B, hipStream_t st) {
 // Tile shape selection; fills the LDS geometry (Cc, span, XS, WS) for the chosen NT/MT.
 template <int MODE>
 hipError_t launch_conv_gemm(GemmConvP p, int B, hipStream_t st) {
-  int MT, NT, cfg;
-  if (p.N <= 80) { if (p.R <= 16) { cfg = 3; MT = 16; NT = 64; } else { cfg = 4; MT = 64; NT = 64; } }
-  else if (p.R <= 16) { cfg = 0; MT = 16; NT = 256; }
-  else if (p.R <= 32) { cfg = 1; MT = 32; NT = 256; }
-  else { cfg = 2; MT = 64; NT = 256; }
+  // Tile choice: the largest tile whose grid still gives every CU about two blocks (256 CUs); small problems (short
+  // sequences, few samples x few row tiles) fall through to the smallest tile = the most blocks.
+  struct Cand { int MT, NT, cfg; };
+  static const Cand cands[] = {{64, 256, 2}, {32, 256, 1}, {64, 64, 4}, {16, 256, 0}, {16, 64, 3}};
+  int MT = 16, NT = 64, cfg = 3;
+  for (const Cand& c : cands) {
+    if (c.MT > 16 && p.R <= 16) continue;
+    if (c.MT > 32 && p.R <= 32) continue;
+    if (c.NT == 256 && p.N <= 80) continue;
+    MT = c.MT; NT = c.NT; cfg = c.cfg;
+    const long blocks = (long)((p.R + c.MT - 1) / c.MT) * ((p.N + c.NT - 1) / c.NT) * p.groups * B;
+    if (blocks >= 512) break;
+  }
   const int hi = (MODE == MODE_DIRECT) ? (p.J - 1) * p.d - p.pad + p.mirror_pad : (MODE == MODE_DOWN ? p.J - 1 : 0);
   const int first = (MODE == MODE_DIRECT) ? -p.pad : (MODE == MODE_DOWN ? 0 : -(p.J - 1));   // position read by column 0, tap 0
   int lo = (MODE == MODE_DIRECT) ? -p.pad - p.mirror_pad : first;
