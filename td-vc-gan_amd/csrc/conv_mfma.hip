@@ -614,8 +614,17 @@ int wgrad_geometry(WgradP& p, int B, int* bpb_out) {
   p.span = ((NTc + hi - p.lo) + 3) / 4 * 4;
   p.XS = ((p.span + 31) / 32) * 32 + 2;     // 2 (mod 32): 16 rows x 2 k-lanes hit 32 distinct banks
   p.AS = ((NTc + 31) / 32) * 32 + 2;
-  // short sequences: loop the whole batch inside one block so that only one slab is written
-  int bpb = (p.N <= 128) ? B : 1;
+  // short sequences: loop several samples inside one block (fewer slabs to write and fold), but keep about two blocks
+  // per CU: a 64-sample batch walked by 64 blocks left three quarters of the chip idle
+  int bpb = 1;
+  if (p.N <= 128) {
+    const int MTg = 16 * M_REP;
+    const long gy = (long)p.groups * ((p.R + MTg - 1) / MTg) * ((p.Cred + 15) / 16) * p.ntiles;
+    long nbg = (512 + gy - 1) / gy;               // batch groups wanted
+    if (nbg > B) nbg = B;
+    if (nbg < 1) nbg = 1;
+    bpb = (int)((B + nbg - 1) / nbg);
+  }
   *bpb_out = bpb;
   return ((B + bpb - 1) / bpb) * p.ntiles;
 }
