@@ -203,6 +203,13 @@ int tdvc_log_l1_bwd(const float* a, const float* b, int64_t n, float floor_, flo
 /* Contrastive InfoNCE (util/losses.py:70-116): cosine logits, softmax, CE against class 0, both
  * directions, fused with its backward. idx_* [B][T][N] int32 are the negative positions (already skipping
  * self, util/losses.py:82-83). loss_out[0] += weight*CE; dX, dY += weight * dCE/d{X,Y} (zero them first). */
+/* Softmax cross-entropy, mean over the batch (F.cross_entropy on the latent classifier's logits, train.py:302, :422).
+ * fwd: *loss_out += weight * mean_b CE(logits[b], labels[b]) and the softmax probabilities go to prob [B][K];
+ * bwd: dlogits = weight / B * (prob - onehot) * upstream[0]. labels are int64 class indices. */
+int tdvc_cross_entropy_fwd(const float* logits, const int64_t* labels, int B, int K, float weight, float* loss_out, float* prob, void* stream);
+int tdvc_cross_entropy_bwd(const float* prob, const int64_t* labels, int B, int K, float weight, const float* upstream, float* dlogits,
+                           void* stream);
+
 /* Sine + noise excitation from a frame-level F0 track (util/__init__.py:22-50, f0_to_excitation): f0 [B][n_frames] in Hz
  * (0 = unvoiced; the last frame is dropped as in the reference), output exc [B][(n_frames-1)*step]. The random draws are
  * inputs: noise_v / noise_u [B][T] standard normal (voiced / unvoiced samples), start_phase [1] in radians (device pointer). */

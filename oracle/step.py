@@ -27,6 +27,7 @@ class StepConfig:
     lambda_spec: float = 5.0
     lambda_cont_emb: float = 10.0
     lambda_corrupted: float = 1.0
+    lambda_latcls: float = 0.0
     lr_g: float = 1e-4
     lr_d: float = 1e-4
     betas: tuple = (0.8, 0.99)
@@ -41,7 +42,8 @@ class StepConfig:
         return StepConfig(no_conv=bool(g('no_conv', False)), lambda_rec=float(g('lambda_rec', 0)),
                           lambda_idt=float(g('lambda_idt', 0)), lambda_feat=float(g('lambda_feat', 0)),
                           lambda_spec=float(g('lambda_spec', 0)), lambda_cont_emb=float(g('lambda_cont_emb', 0)),
-                          lambda_corrupted=float(g('lambda_corrupted', 0)), lr_g=float(g('lr_g', 1e-4)),
+                          lambda_corrupted=float(g('lambda_corrupted', 0)), lambda_latcls=float(g('lambda_latcls', 0)),
+                          lr_g=float(g('lr_g', 1e-4)),
                           lr_d=float(g('lr_d', 1e-4)), betas=tuple(g('adam_beta', (0.8, 0.99))))
 
 
@@ -73,12 +75,19 @@ class AdamW:
 
 
 class TrainStep:
-    def __init__(self, sd_g: dict, sd_d: dict, cfg: StepConfig):
+    def __init__(self, sd_g: dict, sd_d: dict, cfg: StepConfig, sd_c: dict = None):
         self.g = {k: v.clone().requires_grad_(True) for k, v in sd_g.items()}
         self.d = {k: v.clone().requires_grad_(True) for k, v in sd_d.items()}
         self.cfg = cfg
         self.opt_g = AdamW(self.g, cfg.lr_g, cfg.betas, cfg.eps, cfg.weight_decay)
         self.opt_d = AdamW(self.d, cfg.lr_d, cfg.betas, cfg.eps, cfg.weight_decay)
+        # latent classifier (train.py:153-154, optimizer :192 = torch.optim.Adam(lr_d, adam_beta): no weight decay)
+        self.c = None
+        if cfg.lambda_latcls != 0:
+            if sd_c is None:
+                raise ValueError('lambda_latcls != 0 needs the latent classifier state_dict')
+            self.c = {k: v.clone().requires_grad_(True) for k, v in sd_c.items()}
+            self.opt_c = AdamW(self.c, cfg.lr_d, cfg.betas, cfg.eps, 0.0)
 
     # -- D-step ---------------------------------------------------------------------
     def d_losses(self, batch):
@@ -118,6 +127,9 @@ class TrainStep:
                 idt_loss = idt_loss + c.lambda_spec * out['G_loss_idt_spec']
             out['G_loss_idt'] = idt_loss
             total = total + c.lambda_idt * idt_loss
+        if self.c is not None:      # train.py:420-422, :480 — gradient-reversed into the encoder
+            out['G_loss_lat_cls'] = torch.nn.functional.cross_entropy(M.latent_classifier(self.c, emb_real), batch['label_src'])
+            total = total + c.lambda_latcls * out['G_loss_lat_cls']
         if c.lambda_cont_emb > 0 and c.lambda_corrupted:
             emb_cor = M.encoder(self.g, batch['signal_corrupted'])
             out['G_loss_cont_emb'] = L.contrastive(emb_real, emb_cor, idx_x, idx_y)
@@ -132,14 +144,24 @@ class TrainStep:
         dl['D_loss'].backward()
         self.opt_d.step()
         self.opt_d.zero_grad()
+        cl = {}
+        if self.c is not None:      # latent-classifier step (train.py:300-308) on the detached content embedding:
+            with torch.no_grad():   # its gradient into G is dead work (G is not stepped here, grads are zeroed before the G-step)
+                emb = M.encoder(self.g, batch['signal_real'])
+            self.opt_c.zero_grad()
+            logits = M.latent_classifier(self.c, emb)
+            cl['C_loss'] = torch.nn.functional.cross_entropy(logits, batch['label_src'])
+            cl['C_loss'].backward()
+            self.opt_c.step()
+            self.opt_c.zero_grad()
         self.opt_g.zero_grad()
-        for p in self.d.values():  # D grads from the G-step are dead work (Q5): not computed
-            p.requires_grad_(False)
+        for p in list(self.d.values()) + (list(self.c.values()) if self.c is not None else []):
+            p.requires_grad_(False)      # D / C grads from the G-step are dead work (Q5): not computed
         try:
             gl = self.g_losses(batch, idx_x, idx_y)
             gl['G_loss'].backward()
         finally:
-            for p in self.d.values():
+            for p in list(self.d.values()) + (list(self.c.values()) if self.c is not None else []):
                 p.requires_grad_(True)
         self.opt_g.step()
-        return {k: float(v) for k, v in {**dl, **gl}.items()}
+        return {k: float(v) for k, v in {**dl, **cl, **gl}.items()}

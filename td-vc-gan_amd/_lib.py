@@ -102,6 +102,8 @@ SIGNATURES = {
     'tdvc_power_bwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'tdvc_log_l1_fwd': (_i, [_vp, _vp, _i64, _f, _f, _vp, _vp]),
     'tdvc_log_l1_bwd': (_i, [_vp, _vp, _i64, _f, _f, _vp, _vp, _vp]),
+    'tdvc_cross_entropy_fwd': (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
+    'tdvc_cross_entropy_bwd': (_i, [_vp, _vp, _i, _i, _f, _vp, _vp, _vp]),
     'tdvc_f0_to_excitation': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _f, _i, _vp]),
     'tdvc_contrastive_fwd_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp, _vp, _vp, _vp]),
     'tdvc_last_error': (C.c_char_p, []),

@@ -448,6 +448,30 @@ __global__ __launch_bounds__(256) void f0_excitation_kernel(const float* f0, con
   }
 }
 
+// ------------------------------------------------------------------------------ softmax cross-entropy (mean over the batch)
+// F.cross_entropy(logits [B][K], labels) of the latent classifier (train.py:302, :422). One wave per sample; the forward
+// keeps the softmax probabilities for the backward.
+__global__ __launch_bounds__(64) void cross_entropy_fwd_kernel(const float* logits, const int64_t* labels, int K, float w_over_b,
+                                                               float* loss, float* prob) {
+  const int b = blockIdx.x, lane = threadIdx.x;
+  const float* z = logits + (long)b * K;
+  float mx = -1e30f;
+  for (int k = lane; k < K; k += 64) mx = fmaxf(mx, z[k]);
+  for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+  float se = 0.f;
+  for (int k = lane; k < K; k += 64) se += expf(z[k] - mx);
+  se = wave_sum(se);
+  for (int k = lane; k < K; k += 64) prob[(long)b * K + k] = expf(z[k] - mx) / se;
+  if (lane == 0) atomicAdd(loss, (logf(se) + mx - z[labels[b]]) * w_over_b);
+}
+__global__ __launch_bounds__(256) void cross_entropy_bwd_kernel(const float* prob, const int64_t* labels, int B, int K, float w_over_b,
+                                                                const float* up, float* dlogits) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= B * K) return;
+  const int b = i / K, k = i - b * K;
+  dlogits[i] = (prob[i] - (labels[b] == k ? 1.f : 0.f)) * w_over_b * up[0];
+}
+
 }  // namespace
 
 // ================================================================================================ C ABI
@@ -610,5 +634,19 @@ extern "C" int tdvc_f0_to_excitation(const float* f0, const float* noise_v, cons
   if (B <= 0 || n_frames < 2 || step <= 0 || sampling_rate <= 0.f) return tdvc_fail(TDVC_EINVAL, "f0_to_excitation: bad shape");
   hipLaunchKernelGGL(f0_excitation_kernel, dim3(B), dim3(256), 0, (hipStream_t)stream, f0, noise_v, noise_u, start_phase, exc, n_frames, step,
                      sampling_rate, linear);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+
+extern "C" int tdvc_cross_entropy_fwd(const float* logits, const int64_t* labels, int B, int K, float weight, float* loss_out, float* prob,
+                                      void* stream) {
+  if (!logits || !labels || !loss_out || !prob || B <= 0 || K <= 0) return tdvc_fail(TDVC_EINVAL, "cross_entropy_fwd: bad arguments");
+  hipLaunchKernelGGL(cross_entropy_fwd_kernel, dim3(B), dim3(64), 0, (hipStream_t)stream, logits, labels, K, weight / (float)B, loss_out, prob);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+extern "C" int tdvc_cross_entropy_bwd(const float* prob, const int64_t* labels, int B, int K, float weight, const float* upstream,
+                                      float* dlogits, void* stream) {
+  if (!prob || !labels || !upstream || !dlogits || B <= 0 || K <= 0) return tdvc_fail(TDVC_EINVAL, "cross_entropy_bwd: bad arguments");
+  hipLaunchKernelGGL(cross_entropy_bwd_kernel, dim3((B * K + 255) / 256), dim3(256), 0, (hipStream_t)stream, prob, labels, B, K,
+                     weight / (float)B, upstream, dlogits);
   TDVC_CHECK_LAUNCH(); return TDVC_OK;
 }

@@ -49,6 +49,33 @@ class MseConstFn(Function):
         return (None, *grads)
 
 
+class CrossEntropyFn(Function):
+    """F.cross_entropy(logits [B, K], labels [B]) — mean over the batch (latent classifier, train.py:302, :422)."""
+
+    @staticmethod
+    def forward(ctx, logits, labels):
+        logits = logits.contiguous()
+        labels = labels.contiguous().long()
+        B, K = logits.shape
+        out = _ScalarOut.new(logits)
+        prob = torch.empty_like(logits)
+        L.check(L.lib().tdvc_cross_entropy_fwd(logits.data_ptr(), labels.data_ptr(), B, K, 1.0, out.data_ptr(), prob.data_ptr(), _stream(logits)))
+        ctx.save_for_backward(prob, labels)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        prob, labels = ctx.saved_tensors
+        B, K = prob.shape
+        d = torch.empty_like(prob)
+        L.check(L.lib().tdvc_cross_entropy_bwd(prob.data_ptr(), labels.data_ptr(), B, K, 1.0, g.contiguous().data_ptr(), d.data_ptr(), _stream(prob)))
+        return d, None
+
+
+def cross_entropy_loss(logits, labels):
+    return CrossEntropyFn.apply(logits, labels)
+
+
 def lsgan_loss(outs, target):
     return MseConstFn.apply(float(target), *outs)
 

@@ -510,6 +510,7 @@ class LatentClassifier(ArenaModule):
             self.classifier += [ConvParams(nf_prev, nf, ds * 10 + 1, stride=ds, pad=ds * 5), nn.LeakyReLU(SLOPE)]
         self.classifier += [ConvParams(nf, nf, 5, pad=2), nn.LeakyReLU(SLOPE)]
         self.classifier += [ConvParams(nf, num_classes, 3, pad=1, bias=False)]
+        self._pool = {}
 
     def forward(self, x):
         self.begin_forward(x)
@@ -520,5 +521,7 @@ class LatentClassifier(ArenaModule):
         x = convs[-1](x)
         # F.avg_pool1d over the full length, as a fixed 1-tap-per-sample FIR: mean over T
         T = x.shape[2]
-        fir = FixedFIR(torch.full((T,), 1.0 / T), x.shape[1], 1, 0)
-        return fir(x).squeeze(2)
+        key = (T, x.shape[1])
+        if key not in self._pool:        # kept alive: the autograd graph holds only the raw pointer of the taps
+            self._pool[key] = FixedFIR(torch.full((T,), 1.0 / T), x.shape[1], 1, 0)
+        return self._pool[key](x).squeeze(2)

@@ -29,6 +29,7 @@ class StepConfig:
     lambda_spec: float = 5.0
     lambda_cont_emb: float = 10.0
     lambda_corrupted: float = 1.0
+    lambda_latcls: float = 0.0
     lambda_f0: float = 0.0
     lr_g: float = 1e-4
     lr_d: float = 1e-4
@@ -44,13 +45,14 @@ class StepConfig:
         return StepConfig(no_conv=bool(g('no_conv', False)), lambda_rec=float(g('lambda_rec', 0)),
                           lambda_idt=float(g('lambda_idt', 0)), lambda_feat=float(g('lambda_feat', 0)),
                           lambda_spec=float(g('lambda_spec', 0)), lambda_cont_emb=float(g('lambda_cont_emb', 0)),
-                          lambda_corrupted=float(g('lambda_corrupted', 0)), lambda_f0=float(g('lambda_f0', 0)),
+                          lambda_corrupted=float(g('lambda_corrupted', 0)), lambda_latcls=float(g('lambda_latcls', 0)),
+                          lambda_f0=float(g('lambda_f0', 0)),
                           lr_g=float(g('lr_g', 1e-4)), lr_d=float(g('lr_d', 1e-4)),
                           betas=tuple(g('adam_beta', (0.8, 0.99))))
 
 
 class TrainStep:
-    def __init__(self, G, D, cfg: StepConfig, device, reuse_fake=True, grad_sync=None):
+    def __init__(self, G, D, cfg: StepConfig, device, reuse_fake=True, grad_sync=None, C=None):
         if cfg.lambda_rec > 0:
             raise NotImplementedError('lambda_rec > 0 (cycle reconstruction branch, train.py:344-361) is not built yet')
         self.G, self.D, self.cfg, self.device = G, D, cfg, torch.device(device)
@@ -61,6 +63,16 @@ class TrainStep:
         self.opt_d = FlatAdamW(da, cfg.lr_d, cfg.betas, cfg.eps, cfg.weight_decay)
         G.weights_frozen(True); D.weights_frozen(True)     # effective weights are rebuilt right after each update
         ga.materialize(); da.materialize()
+        # latent classifier (train.py:153-154; optimizer :192 is torch.optim.Adam(lr_d, adam_beta): no weight decay)
+        self.C = None
+        if cfg.lambda_latcls != 0:
+            if C is None:
+                raise ValueError('lambda_latcls != 0 needs the LatentClassifier module')
+            self.C = C
+            ca = C.ensure_arena(self.device)
+            self.opt_c = FlatAdamW(ca, cfg.lr_d, cfg.betas, cfg.eps, 0.0)
+            C.weights_frozen(True)
+            ca.materialize()
 
     # -------------------------------------------------------------------------------------------
     def _generate(self, batch):
@@ -95,7 +107,9 @@ class TrainStep:
             (fake, fake_subs) = self._gen_out[0]
         else:
             with torch.no_grad():
-                (fake, fake_subs) = self._generate(batch)[0]
+                gen = self._generate(batch)
+                (fake, fake_subs) = gen[0]
+                self._emb_for_c = gen[2]
         real = batch['signal_real']
         B = real.shape[0]
         self._real_subs = D.get_subsamples(real)
@@ -126,6 +140,8 @@ class TrainStep:
         real = batch['signal_real']
         B = real.shape[0]
         D.arena.wgrad_enabled = False                     # Q5
+        if self.C is not None:
+            self.C.arena.wgrad_enabled = False            # the classifier's own grads from the G-step are dead work too
         try:
             if self.reuse_fake:
                 (fake, fake_subs), idt_pair, emb_real, emb_cor = self._gen_out
@@ -169,6 +185,10 @@ class TrainStep:
                 if l_idt is not None:
                     log['G_loss_idt'] = l_idt.detach()
                     total = total + c.lambda_idt * l_idt
+            if self.C is not None:      # train.py:420-422, :480 -- gradient-reversed into the encoder
+                l_cls = LS.cross_entropy_loss(self.C(emb_real), batch['label_src'])
+                log['G_loss_lat_cls'] = l_cls.detach()
+                total = total + c.lambda_latcls * l_cls
             if emb_cor is not None:
                 l_con = LS.contrastive_loss(emb_real, emb_cor, num_negatives=c.n_neg, temp=0.1, idx_x=idx_x, idx_y=idx_y)
                 log['G_loss_cont_emb'] = l_con.detach()
@@ -177,14 +197,33 @@ class TrainStep:
             total.backward()
         finally:
             D.arena.wgrad_enabled = True
+            if self.C is not None:
+                self.C.arena.wgrad_enabled = True
         log['G_loss'] = total.detach()
 
     def run(self, batch, idx_x=None, idx_y=None):
         """One iteration. Returns {tag: 1-element device tensor}; no host synchronisation inside."""
         log = {}
         self.d_step(batch, log)
+        if self.C is not None:
+            self.c_step(batch, log)
         self.g_step(batch, log, idx_x, idx_y)
         return log
+
+    def c_step(self, batch, log):
+        """Latent-classifier step (train.py:300-308) on the detached content embedding of the D-step's generator forward:
+        the gradient it would send into G is dead work (G is not stepped here and its grads are zeroed before the G-step)."""
+        C = self.C
+        emb = self._gen_out[2] if self.reuse_fake else self._emb_for_c
+        logits = C(emb.detach())
+        c_loss = LS.cross_entropy_loss(logits, batch['label_src'])
+        self.opt_c.zero_grad()
+        c_loss.backward()
+        if self.grad_sync is not None:
+            self.grad_sync.all_reduce(C.arena)
+        self.opt_c.step(grad_scale=1.0 if self.grad_sync is None else self.grad_sync.scale)
+        C.arena.materialize()
+        log['C_loss'] = c_loss.detach()
 
     def capture(self, batch, idx_x, idx_y, warmup=2):
         """Capture the whole iteration (≈3.5k kernel launches, both backward passes, both AdamW updates) into one

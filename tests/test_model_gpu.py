@@ -230,3 +230,61 @@ def test_f0_to_excitation_device_vs_reference_golden(dev):
     # default path: draws on the device, same statistics
     exc2 = U.f0_to_excitation(t(g['f0']), int(g['step']))
     assert exc2.shape == ref.shape and abs(float(exc2.std()) - float(ref.std())) < 0.1 * float(ref.std())
+
+
+def test_train_step_with_latent_classifier_vs_golden(dev):
+    """the iteration with lambda_latcls = 1 (latent-classifier step with Adam + gradient-reversed
+    classification term in the G loss) vs the fixture produced by the reference's own Generator / Discriminator /
+    LatentClassifier modules (tests/golden/step_latcls.json, oracle/make_golden_latcls.py)."""
+    P = pkg()
+    gold = json.load(open(os.path.join(GOLDEN, 'step_latcls.json')))
+    hp = P.hparams.HParam(os.path.join(os.path.dirname(GOLDEN), '..', 'config', 'conv_enc-stage1.yaml'))
+    train = dict(hp.train); train['lambda_latcls'] = 1.0
+    cfg = P.train_step.StepConfig.from_hparams(train)
+    G, D = build_models(dev)
+    C = P.modules.LatentClassifier(16, 128)
+    C.load_state_dict(filled_sd('C')); C.ensure_arena(dev)
+    ts = P.train_step.TrainStep(G, D, cfg, dev, C=C)
+    T, B = gold['T'], gold['B']
+    bt = to_dev(P.synth.make_batch(B, T, seed=1234, conversion=True), dev)
+    for it, ref in enumerate(gold['losses']):
+        ix = P.synth.contrastive_indices(B, T // 320, cfg.n_neg, seed=100 + 2 * it)
+        iy = P.synth.contrastive_indices(B, T // 320, cfg.n_neg, seed=101 + 2 * it)
+        log = ts.run(bt, ix, iy)
+        torch.cuda.synchronize()
+        errs = {k: abs(float(log[k]) - v) / (abs(v) + 1e-12) for k, v in ref.items()}
+        tol = {k: TOL for k in errs}
+        assert all(errs[k] < tol[k] for k in errs), (it, errs)
+    for name, model, key in (('G', G, 'params_G'), ('D', D, 'params_D'), ('C', C, 'params_C')):
+        bad = {}
+        for k, v in model.state_dict().items():
+            s, a = gold[key][k]
+            got_a = float(v.double().abs().sum())
+            if abs(got_a - a) > TOL * (abs(a) + 1e-12):
+                bad[k] = (got_a, a)
+        assert not bad, (name, dict(list(bad.items())[:5]))
+
+
+def test_latent_classifier_grads_vs_oracle(dev):
+    """LatentClassifier (gradient-reversal + 3 strided convs + 2 convs + mean) + cross-entropy: loss, input gradient and every
+    parameter gradient against the CPU oracle (model/latent_classifier.py:8-39, model/grad_rev.py:3-17)."""
+    from oracle import model as OM
+    P = pkg()
+    C = P.modules.LatentClassifier(16, 128)
+    C.load_state_dict(filled_sd('C')); C.ensure_arena(dev)
+    rs = np.random.RandomState(9)
+    emb = torch.from_numpy(rs.randn(4, 128, 50).astype(np.float32))
+    lab = torch.from_numpy(rs.randint(0, 16, size=4).astype(np.int64))
+    sc = {k: v.clone().requires_grad_(True) for k, v in filled_sd('C').items()}
+    eo = emb.clone().requires_grad_(True)
+    lo = torch.nn.functional.cross_entropy(OM.latent_classifier(sc, eo), lab)
+    lo.backward()
+    ed = emb.to(dev).requires_grad_(True)
+    C.arena.zero_grad()
+    l = P.losses.cross_entropy_loss(C(ed), lab.to(dev))
+    l.backward()
+    torch.cuda.synchronize()
+    assert abs(float(l) - float(lo)) < 1e-5 * abs(float(lo))
+    errs = {k: rel_l2(p.grad, sc[k].grad) for k, p in C.named_parameters()}
+    errs['d_emb'] = rel_l2(ed.grad, eo.grad)
+    assert max(errs.values()) < 1e-4, errs

@@ -135,3 +135,22 @@ def test_excitation_restatement_vs_reference_golden():
     ours = synth.excitation_from_f0(g['f0'], Replay(), int(g['step']))
     assert ours.shape == g['exc'].shape
     assert float(np.abs(ours - g['exc']).max()) < 2e-5      # amplitude 0.1; the reference accumulates the phase in fp32
+
+
+def test_oracle_step_with_latent_classifier_vs_golden():
+    """oracle.step.TrainStep with lambda_latcls = 1 against the reference-module iteration (tests/golden/step_latcls.json)."""
+    import importlib
+    from oracle import step as OS
+    synth = importlib.import_module('td-vc-gan_amd.synth')
+    hparams = importlib.import_module('td-vc-gan_amd.hparams')
+    gold = json.load(open(os.path.join(GOLDEN, 'step_latcls.json')))
+    hp = hparams.HParam(os.path.join(os.path.dirname(GOLDEN), '..', 'config', 'conv_enc-stage1.yaml'))
+    train = dict(hp.train); train['lambda_latcls'] = 1.0
+    cfg = OS.StepConfig.from_hparams(train)
+    ost = OS.TrainStep(filled_sd('G'), filled_sd('D'), cfg, filled_sd('C'))
+    bt = synth.make_batch(gold['B'], gold['T'], seed=1234, conversion=True)
+    ref = gold['losses'][0]
+    log = ost.run(bt, synth.contrastive_indices(gold['B'], gold['T'] // 320, cfg.n_neg, seed=100),
+                  synth.contrastive_indices(gold['B'], gold['T'] // 320, cfg.n_neg, seed=101))
+    errs = {k: abs(log[k] - v) / (abs(v) + 1e-12) for k, v in ref.items()}
+    assert max(errs.values()) < 1e-5, errs
