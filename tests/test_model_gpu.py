@@ -288,3 +288,31 @@ def test_latent_classifier_grads_vs_oracle(dev):
     errs = {k: rel_l2(p.grad, sc[k].grad) for k, p in C.named_parameters()}
     errs['d_emb'] = rel_l2(ed.grad, eo.grad)
     assert max(errs.values()) < 1e-4, errs
+
+
+def test_inference_path_long_utterance_vs_oracle(dev, tmp_path):
+    """checkpoint interchange (a state_dict file with the reference's keys, loaded with weights_only=True),
+    generator built from the reference config section, excitation on the device, ONE forward-only pass of a
+    test.max_segment-long utterance (71680 samples, batch 1) against the CPU oracle."""
+    from oracle import model as OM
+    P = pkg()
+    ckpt = tmp_path / 'latest-G.pt'
+    torch.save(filled_sd('G'), ckpt)
+    hp = P.hparams.HParam(os.path.join(os.path.dirname(GOLDEN), '..', 'config', 'conv_enc-stage1.yaml'))
+    G = P.infer.build_generator(hp.model.generator, 16, dev)
+    P.infer.load_generator_checkpoint(G, str(ckpt))
+    T = 71680
+    rs = np.random.RandomState(31)
+    f0_src, f0_tgt = P.synth.make_f0(rs, 1, T), P.synth.make_f0(rs, 1, T)
+    x = torch.from_numpy((rs.randn(1, 1, T) * 0.03).astype(np.float32))
+    c_tgt = torch.zeros(1, 16); c_tgt[0, 5] = 1.0
+    f0c = P.infer.shift_f0(torch.from_numpy(f0_src).to(dev), torch.from_numpy(f0_tgt).to(dev))
+    noise = (torch.from_numpy(rs.randn(1, 1, T).astype(np.float32)).to(dev), torch.from_numpy(rs.randn(1, 1, T).astype(np.float32)).to(dev))
+    phi0 = torch.tensor([1.234], device=dev)
+    y = P.infer.convert(G, x.to(dev), c_tgt.to(dev), f0c, noise=noise, start_phase=phi0)
+    exc = P.util.f0_to_excitation(f0c, 64, noise=noise, start_phase=phi0)
+    torch.cuda.synchronize()
+    assert y.shape == (1, 1, T) and not y.requires_grad
+    with torch.no_grad():
+        yo, _, _ = OM.generator(filled_sd('G'), x, c_tgt, exc.cpu())
+    assert rel_l2(y, yo) < TOL
