@@ -145,17 +145,29 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 12 ? 2 : ((M_REP * N_REP >= 
         for (int e = 0; e < 3; ++e) k3v[nt][e] = cv ? p.k3[((long)b * p.Cin + c) * 3 + e] : 0.f;
       }
       const int mtl = (p.span + 15) >> 4;
+      // per-lane operands of the pre-pass that do not depend on the time tile: the (channel, tap) walk of the A operand
+      // and the whole B operand (W0x chunk) live in registers for all the time tiles of this chunk
+      int eoff[6]; float bwr[2][6];
+#pragma unroll
+      for (int st = 0; st < 6; ++st) {
+        const int k = st * 4 + kq;
+        const int ce = (k * 11) >> 5;                       // k / 3 for k < 32
+        eoff[st] = (k < kv) ? ce * p.ES + (k - ce * 3) : -1;
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) bwr[nt][st] = (nt < ntl && k < kv) ? wx[(nt * 16 + ln) * WX + k] : 0.f;
+      }
       for (int mtile = wave; mtile < mtl; mtile += 4) {
         f32x4 pa[2] = {(f32x4){0.f, 0.f, 0.f, 0.f}, (f32x4){0.f, 0.f, 0.f, 0.f}};
-        for (int st = 0; st * 4 < kv; ++st) {
-          const int k = st * 4 + kq;
-          const int ce = k / 3, j = k - ce * 3;
-          const float a = (k < kv) ? es[ce * p.ES + mtile * 16 + ln + j] : 0.f;
+        const float* ep = es + mtile * 16 + ln;
 #pragma unroll
-          for (int nt = 0; nt < 2; ++nt) {
-            if (nt >= ntl) continue;
-            const float bw = (k < kv) ? wx[(nt * 16 + ln) * WX + k] : 0.f;
-            pa[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bw, pa[nt], 0, 0, 0);
+        for (int st = 0; st < 6; ++st) {
+          if (st * 4 < kv) {
+            const float a = eoff[st] >= 0 ? ep[eoff[st]] : 0.f;
+#pragma unroll
+            for (int nt = 0; nt < 2; ++nt) {
+              if (nt >= ntl) continue;
+              pa[nt] = __builtin_amdgcn_mfma_f32_16x16x4f32(a, bwr[nt][st], pa[nt], 0, 0, 0);
+            }
           }
         }
         const int t0 = mtile * 16 + kq * 4;                 // lane owns 4 consecutive positions of channel (nt*16 + ln)
