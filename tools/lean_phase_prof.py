@@ -78,6 +78,18 @@ def main():
             print(f'{name:10s} {which:6s} blocks={r.shape[0]:6d} wall={e0.elapsed_time(e1) * 1e3:7.1f} us  block cycles mean={tot.mean():9.0f} '
                   f'(= {tot.mean() / clk:6.1f} us @ {clk:5.0f} MHz)  ideal MFMA/SIMD-wave={fl / (r.shape[0] * 4) / 2048 * 32:8.0f} cyc', flush=True)
             print('     mean ' + '  '.join(f'{n}={r[:, i].mean():8.0f}' for i, n in enumerate(NAMES)) + f'  vmwait={r[:, 8].mean():8.0f}', flush=True)
+            if which != 'wgrad':
+                full = buf.view(-1, 10).cpu().double()
+                nt = (T + 255) // 256 if T > 80 else 1
+                for cand in (256, 64):
+                    gx = (T + cand - 1) // cand
+                    if r.shape[0] % gx == 0: nt = gx
+                nb = r.shape[0]
+                ids = torch.arange(nb) % nt
+                fb = full[:nb]
+                for nm, sel in (('end ', (ids == 0) | (ids == nt - 1)), ('mid ', (ids != 0) & (ids != nt - 1))):
+                    if sel.any():
+                        print(f'     {nm} ' + '  '.join(f'{n}={fb[sel][:, i].mean():8.0f}' for i, n in enumerate(NAMES)) + f'  total={(fb[sel][:, :7].sum(1) + fb[sel][:, 8]).mean():8.0f}  (gx={nt})', flush=True)
             print('     p50  ' + '  '.join(f'{n}={r[:, i].median():8.0f}' for i, n in enumerate(NAMES)) + f'  total p50={tot.median():8.0f} max={tot.max():8.0f}', flush=True)
 
 
