@@ -83,35 +83,42 @@ __global__ __launch_bounds__(256, 2) void film_cond0_bwd_kernel(const Cond0BwdP 
 
   int b = __builtin_amdgcn_readfirstlane(q_begin / p.ntile);
   int tile = q_begin - b * p.ntile;
+  // Register prefetch one chunk ahead (T14): the loads of chunk q+1 are issued before the MFMAs of chunk q and stored to
+  // LDS after them, so their latency hides under the matrix work.
+  f32x4 v[CB_NP], ex;
+  const int er = tid / CB_NV, ev = tid - er * CB_NV;           // tid < 144: one float4 of the excitation tile
+  auto issue = [&](int bb, int tt) {    // stage d_cv0 [nc][72] and exc [8][72]; columns outside [0, T) and rows >= nc load as zero
+    const int n0 = tt * CB_NT;
+    const srd_t drs = make_srd(p.dcv + (long)bb * p.dcv_bs, p.nc * T * 4);
+    const int qc = n0 - 4 + 4 * vv;
+    int vo = (ract && qc >= 0 && qc < T) ? (rsub * T + qc) * 4 : 0x7f000000;
+#pragma unroll
+    for (int i = 0; i < CB_NP; ++i) { v[i] = buf_load4(drs, vo); vo += CB_RP * T * 4; }
+    const srd_t ers = make_srd(p.exc + (long)bb * p.exc_bs, 8 * T * 4);
+    const int eq = n0 - 4 + 4 * ev;
+    ex = buf_load4(ers, (er < 8 && eq >= 0 && eq < T) ? (er * T + eq) * 4 : 0x7f000000);
+  };
+  issue(b, tile);
   for (int q = q_begin; q < q_end; ++q) {
     const int n0 = tile * CB_NT;
+    int nb = b, ntile_i = tile + 1;
+    if (ntile_i == p.ntile) { ntile_i = 0; ++nb; }
     __syncthreads();                                // the previous chunk's fragments are consumed (and wsm is written)
-    {   // ---- stage d_cv0 [nc][72] and exc [8][72]; columns outside [0, T) and rows >= nc load as zero
-      const srd_t drs = make_srd(p.dcv + (long)b * p.dcv_bs, p.nc * T * 4);
-      const int qc = n0 - 4 + 4 * vv;
-      int vo = (ract && qc >= 0 && qc < T) ? (rsub * T + qc) * 4 : 0x7f000000;
-      f32x4 v[CB_NP];
+    if (ract) {
 #pragma unroll
-      for (int i = 0; i < CB_NP; ++i) { v[i] = buf_load4(drs, vo); vo += CB_RP * T * 4; }
-      const srd_t ers = make_srd(p.exc + (long)b * p.exc_bs, 8 * T * 4);
-      const int er = tid / CB_NV, ev = tid - er * CB_NV;       // tid < 144: one float4 of the excitation tile
-      const int eq = n0 - 4 + 4 * ev;
-      const f32x4 ex = buf_load4(ers, (er < 8 && eq >= 0 && eq < T) ? (er * T + eq) * 4 : 0x7f000000);
-      if (ract) {
-#pragma unroll
-        for (int i = 0; i < CB_NP; ++i) {
-          if (i * CB_RP + rsub < CB_ROWS) {
-            f32x2* d = reinterpret_cast<f32x2*>(ds + lds_off + i * CB_RP * CB_S);
-            d[0] = (f32x2){v[i][0], v[i][1]}; d[1] = (f32x2){v[i][2], v[i][3]};
-          }
+      for (int i = 0; i < CB_NP; ++i) {
+        if (i * CB_RP + rsub < CB_ROWS) {
+          f32x2* d = reinterpret_cast<f32x2*>(ds + lds_off + i * CB_RP * CB_S);
+          d[0] = (f32x2){v[i][0], v[i][1]}; d[1] = (f32x2){v[i][2], v[i][3]};
         }
       }
-      if (er < 8) {
-        f32x2* d = reinterpret_cast<f32x2*>(es + er * CB_S + 4 * ev);
-        d[0] = (f32x2){ex[0], ex[1]}; d[1] = (f32x2){ex[2], ex[3]};
-      }
+    }
+    if (er < 8) {
+      f32x2* d = reinterpret_cast<f32x2*>(es + er * CB_S + 4 * ev);
+      d[0] = (f32x2){ex[0], ex[1]}; d[1] = (f32x2){ex[2], ex[3]};
     }
     __syncthreads();
+    if (q + 1 < q_end) issue(nb, ntile_i);
 
     // ---- (b) dW / dk3 partials: this wave's 16 time steps
 #pragma unroll
@@ -150,9 +157,7 @@ __global__ __launch_bounds__(256, 2) void film_cond0_bwd_kernel(const Cond0BwdP 
       if (ln < 8 && t0 < T) *reinterpret_cast<f32x4*>(p.dexc + (long)b * p.dexc_bs + (long)ln * T + t0) = d1;
     }
 
-    // ---- next chunk; dk3 partials leave the registers when the sample changes
-    int nb = b, ntile_i = tile + 1;
-    if (ntile_i == p.ntile) { ntile_i = 0; ++nb; }
+    // ---- dk3 partials leave the registers when the sample changes
     if (nb != b || q + 1 == q_end) {
       if (kq == 2) {
 #pragma unroll
