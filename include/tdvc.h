@@ -140,6 +140,15 @@ typedef struct {
 size_t tdvc_film_cond0_bwd_workspace(int32_t B, int32_t T, int32_t n_cond, int32_t n_var);
 int tdvc_film_cond0_bwd(const tdvc_film_cond0_bwd_args* a, void* stream);
 
+/* k3 [B][n_cond][3] = cond_var.0 restricted to the n_const time-constant speaker-embedding channels of its input,
+ * evaluated on a length-3 constant signal with the conv's zero 'same' padding (bias b0 included; w0 = effective weight
+ * [n_cond][n_cond][3], emb [B][n_const]). bwd: demb [B][n_const] (optional), and the matching window of dw0 / db0 is
+ * accumulated (+=, optional). Replaces three conv launches per FiLM block on a 3-sample sequence. */
+int tdvc_film_k3_fwd(const float* emb, int64_t emb_bs, const float* w0, const float* b0, float* k3, int32_t B, int32_t n_const,
+                     int32_t n_cond, void* stream);
+int tdvc_film_k3_bwd(const float* dk3, const float* emb, int64_t emb_bs, const float* w0, float* demb, float* dw0, float* db0,
+                     int32_t B, int32_t n_const, int32_t n_cond, void* stream);
+
 /* Multi-tensor weight norm (old-style nn.utils.weight_norm, dim=0; model/generator.py:14,
  * util/__init__.py:16-20, model/discriminator.py:11): w[row] = g[row] * v[row] / ||v[row]||, one wave per
  * dim-0 slice, every weight-normed tensor of a model in ONE launch. `params` is the model's flat parameter

@@ -200,6 +200,85 @@ __global__ __launch_bounds__(256, 2) void film_cond0_bwd_kernel(const Cond0BwdP 
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// k3 = cond_var.0 restricted to the time-constant speaker-embedding channels, evaluated on a length-3 constant signal
+// (zero 'same' padding): position 0 misses tap 0, position 2 misses tap 2. A [B x n_const] . [n_const x 3 nc] product per
+// FiLM block -- far too small for the conv kernels (three launches + a slab fold per block were ~3 ms per step).
+__global__ __launch_bounds__(256) void film_k3_fwd_kernel(const float* emb, long emb_bs, const float* w0, const float* b0, float* k3,
+                                                          int B, int n_const, int nc) {
+  // one wave per output channel c: lanes run along the (contiguous) weight row, which stays in registers for all samples
+  const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= nc) return;
+  const float* w = w0 + (long)c * nc * 3;
+  float wa[4], wb[4], wc[4];                       // n_const <= 256
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ci = lane + 64 * i;
+    const bool ok = ci < n_const;
+    wa[i] = ok ? w[ci * 3] : 0.f; wb[i] = ok ? w[ci * 3 + 1] : 0.f; wc[i] = ok ? w[ci * 3 + 2] : 0.f;
+  }
+  const float bias = b0 ? b0[c] : 0.f;
+  const int b_end = min(B, ((int)blockIdx.y + 1) * 4);
+  for (int b = blockIdx.y * 4; b < b_end; ++b) {       // 4 samples per block: enough blocks to cover the latency of this tiny op
+    const float* e = emb + (long)b * emb_bs;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ci = lane + 64 * i;
+      const float ev = ci < n_const ? e[ci] : 0.f;
+      s0 += ev * (wb[i] + wc[i]); s1 += ev * ((wa[i] + wb[i]) + wc[i]); s2 += ev * (wa[i] + wb[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (lane == 0) { float* o3 = k3 + ((long)b * nc + c) * 3; o3[0] = s0 + bias; o3[1] = s1 + bias; o3[2] = s2 + bias; }
+  }
+}
+
+// blocks [0, nA): weight / bias gradients, thread = (c, ci), sequential (deterministic) sum over the batch, accumulated into
+// the arena; blocks [nA, ...): embedding gradient, thread = (b, ci).
+__global__ __launch_bounds__(256) void film_k3_bwd_kernel(const float* dk3, const float* emb, long emb_bs, const float* w0, float* demb,
+                                                          float* dw0, float* db0, int B, int n_const, int nc, int nA) {
+  if ((int)blockIdx.x < nA) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nc * n_const || !dw0) return;
+    const int c = idx / n_const, ci = idx - c * n_const;
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, gb = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float* d = dk3 + ((long)b * nc + c) * 3;
+      const float d0 = d[0], d1 = d[1], d2 = d[2], ev = emb[(long)b * emb_bs + ci];
+      g0 += ev * (d1 + d2); g1 += ev * ((d0 + d1) + d2); g2 += ev * (d0 + d1); gb += (d0 + d1) + d2;
+    }
+    float* o = dw0 + ((long)c * nc + ci) * 3;
+    o[0] += g0; o[1] += g1; o[2] += g2;
+    if (ci == 0 && db0) db0[c] += gb;
+  } else {
+    // embedding gradient: block = (sample b, 32 embedding channels); the 8 thread groups split the sum over the nc
+    // output channels and are folded through LDS in a fixed order (deterministic)
+    __shared__ float part[8][32];
+    const int blk = (int)blockIdx.x - nA;
+    const int per_b = (n_const + 31) / 32;
+    const int b = blk / per_b, ci = (blk - b * per_b) * 32 + (threadIdx.x & 31), cg = threadIdx.x >> 5;
+    float a = 0.f;
+    if (ci < n_const) {
+      for (int c = cg; c < nc; c += 8) {
+        const float* d = dk3 + ((long)b * nc + c) * 3;
+        const float* w = w0 + ((long)c * nc + ci) * 3;
+        const float d0 = d[0], d1 = d[1], d2 = d[2];
+        a += w[0] * (d1 + d2) + w[1] * ((d0 + d1) + d2) + w[2] * (d0 + d1);
+      }
+    }
+    part[cg][threadIdx.x & 31] = a;
+    __syncthreads();
+    if (cg == 0 && ci < n_const) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) t += part[g][threadIdx.x];
+      demb[(long)b * n_const + ci] = t;
+    }
+  }
+}
+
 static void cond0_plan(int B, int T, int* ntile, int* tpb, int* nblocks) {
   *ntile = (T + CB_NT - 1) / CB_NT;
   const long nchunks = (long)B * (*ntile);
@@ -253,4 +332,22 @@ extern "C" int tdvc_film_cond0_bwd(const tdvc_film_cond0_bwd_args* a, void* stre
     if (e != hipSuccess) return tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));
   }
   return TDVC_OK;
+}
+
+extern "C" int tdvc_film_k3_fwd(const float* emb, int64_t emb_bs, const float* w0, const float* b0, float* k3, int32_t B, int32_t n_const,
+                                int32_t n_cond, void* stream) {
+  if (!emb || !w0 || !k3 || B <= 0 || n_const <= 0 || n_const > 256 || n_cond < n_const) return tdvc_fail(TDVC_EINVAL, "film_k3_fwd: bad arguments");
+  hipLaunchKernelGGL(film_k3_fwd_kernel, dim3((n_cond + 3) / 4, (B + 3) / 4), dim3(256), 0, (hipStream_t)stream, emb, (long)emb_bs, w0, b0, k3, B,
+                     n_const, n_cond);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+
+extern "C" int tdvc_film_k3_bwd(const float* dk3, const float* emb, int64_t emb_bs, const float* w0, float* demb, float* dw0, float* db0,
+                                int32_t B, int32_t n_const, int32_t n_cond, void* stream) {
+  if (!dk3 || !emb || !w0 || B <= 0 || n_const <= 0 || n_cond < n_const) return tdvc_fail(TDVC_EINVAL, "film_k3_bwd: bad arguments");
+  const int nA = dw0 ? (n_cond * n_const + 255) / 256 : 0, nB = demb ? B * ((n_const + 31) / 32) : 0;
+  if (nA + nB == 0) return TDVC_OK;
+  hipLaunchKernelGGL(film_k3_bwd_kernel, dim3(nA + nB), dim3(256), 0, (hipStream_t)stream, dk3, emb, (long)emb_bs, w0, demb, dw0, db0, B,
+                     n_const, n_cond, nA);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
 }

@@ -182,11 +182,11 @@ class FiLMResnetBlock(nn.Module):
 
     def forward(self, x, c=None, acc=None, scale=1.0):
         """c: None (encoder), a dense [B,n_const+n_var,T] conditioning tensor (reference formulation), or a
-        (emb3 [B,n_const,3], exc [B,n_var,T]) pair for the split formulation."""
+        (emb [B,n_const] or emb3 [B,n_const,3], exc [B,n_var,T]) pair for the split formulation."""
         gb = None
         if isinstance(c, tuple):
             emb3, exc = c
-            k3 = ops.conv(emb3, self.spec_const)
+            k3 = ops.film_k3(emb3, self.spec_const) if emb3.dim() == 2 else ops.conv(emb3, self.spec_const)
             if FUSED_COND and exc.shape[2] % 4 == 0:
                 gb = ops.film_cond(exc, k3, self.spec_var, self.cond_var[2].spec)
             else:
@@ -306,8 +306,8 @@ class Decoder(nn.Module):
             # the reference raises UnboundLocalError here (Q8); be explicit instead
             raise RuntimeError('Decoder.forward needs c_var (the F0 excitation): the reference has no path without it')
         pyr = self.get_scaled_conditioning(c_var.contiguous().float())
-        if self.split_cond:   # speaker embedding as a length-3 constant signal: [B,128] -> [B,128,3]
-            emb3 = ops.ConcatCondFn.apply(c, torch.empty((c.shape[0], 0, 3), dtype=torch.float32, device=c.device))
+        if self.split_cond:   # the speaker embedding [B,128] itself: its conv over a length-3 constant signal is tdvc_film_k3
+            emb3 = c.contiguous().float()
         subs = []
         scale = 0
         final_conv = len(self.decoder) - 2

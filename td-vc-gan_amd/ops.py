@@ -279,6 +279,41 @@ class FilmCondFn(Function):
         return dexc, dk3, None, None, None
 
 
+class FilmK3Fn(Function):
+    """k3 [B, nc, 3]: cond_var.0 on the time-constant speaker-embedding channels, as a length-3 constant signal
+    (model/generator.py:86-92 with the exact split of SURVEY §2.2). emb: [B, n_const]."""
+
+    @staticmethod
+    def forward(ctx, emb, token, spec_const):
+        emb = emb.contiguous()
+        B, n_const = emb.shape
+        nc = spec_const.cout
+        s = spec_const.slot
+        k3 = torch.empty((B, nc, 3), dtype=torch.float32, device=emb.device)
+        L.check(L.lib().tdvc_film_k3_fwd(emb.data_ptr(), emb.stride(0), s.w, s.b or None, k3.data_ptr(), B, n_const, nc, _stream(emb)))
+        ctx.spec = spec_const
+        ctx.save_for_backward(emb)
+        return k3
+
+    @staticmethod
+    def backward(ctx, dk3):
+        (emb,) = ctx.saved_tensors
+        dk3 = dk3.contiguous()
+        B, n_const = emb.shape
+        s = ctx.spec.slot
+        want_w = s.trainable and (s.arena is None or s.arena.wgrad_enabled)
+        demb = torch.empty_like(emb) if ctx.needs_input_grad[0] else None
+        L.check(L.lib().tdvc_film_k3_bwd(dk3.data_ptr(), emb.data_ptr(), emb.stride(0), s.w, demb.data_ptr() if demb is not None else None,
+                                         s.dw if want_w else None, (s.db or None) if want_w else None, B, n_const, ctx.spec.cout, _stream(dk3)))
+        if want_w and s.arena is not None:
+            s.arena.queue_finish()
+        return demb, None, None
+
+
+def film_k3(emb, spec_const):
+    return FilmK3Fn.apply(emb, _token(spec_const), spec_const)
+
+
 def film_cond(exc, k3, spec_var, spec2):
     return FilmCondFn.apply(exc, k3, _token(spec_var, spec2), spec_var, spec2)
 
