@@ -204,7 +204,8 @@ def main():
         roof['mfma_kernel'] = dict(kernel=f'conv_lean_kernel<4,4,1,4,ACT,FWD> FiLM cond_var.2 136->128 k3 T=4000 B={BL} fwd', bound='mfma',
                                    achieved=fl2 / (ms2 * 1e-3) / 1e12, peak=MFMA_F32_PEAK_TF, unit='TFLOP/s',
                                    frac=fl2 / (ms2 * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, ms_per_launch=ms2)
-        out = dict(metric='audio-seconds/sec (G+D train step, stage-1)', value=value, unit='audio-seconds/sec', n_gpus=world,
+        stage = 'stage-1' if 'stage1' in args.config else args.config
+        out = dict(metric=f'audio-seconds/sec (G+D train step, {stage})', value=value, unit='audio-seconds/sec', n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
                    scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
                    config=dict(workload=f'config/{args.config}.yaml full D+G iteration, {B} x 1 s @16 kHz per GPU, NUM_SPK=16, '
