@@ -305,7 +305,54 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 12 ? 2 : ((M_REP * N_REP >= 
     }
     if (s < nsteps) mma(0);
 
-    if (needL || needR) {   // reflect-pad fold (input-grad of a reflect conv): edge waves only
+    if (M_REP >= 2 && (needL || needR)) {   // reflect-pad fold (input-grad of a reflect conv): edge waves only
+      // Per side, only the 16-column sub-tiles that hold mirrored columns take part (pad <= 25: one or two of them). Each
+      // runs a software-pipelined (tap, channel-group) loop into a temporary accumulator that is then added to the
+      // sub-tile's own accumulators, so the extra work of the blocks at the sequence ends stays a fraction of a chunk.
+      for (int side = 0; side < 2; ++side) {
+        if (side == 0 ? !needL : !needR) continue;
+#pragma unroll
+        for (int n = 0; n < N_REP; ++n) {
+          const int ca = n0 + wcol0 + n * 16, cb = ca + 15;
+          const int use = __builtin_amdgcn_readfirstlane(side == 0 ? (ca <= p.mirror && cb >= 1) : (ca <= p.T - 2 && cb >= p.T - 1 - p.mirror));
+          if (!use) continue;
+          const int u = ca + ln;
+          bool mv; int mb;
+          if (side == 0) { mv = (u >= 1 && u <= p.mirror && u < p.T); mb = -u - n0 + p.i0; }
+          else { mv = (u >= p.T - 1 - p.mirror && u <= p.T - 2 && u >= 0); mb = 2 * (p.T - 1) - u - n0 + p.i0; }
+          f32x4 tacc[M_REP];
+#pragma unroll
+          for (int m = 0; m < M_REP; ++m) tacc[m] = (f32x4){0.f, 0.f, 0.f, 0.f};
+          const int nit = p.K * csteps;
+          float wq[2][M_REP], xq[2];
+          int mj = 0, mcs = 0;
+          auto mload = [&](int buf) {
+            const float* wj = w_lane + (p.flip ? p.K - 1 - mj : mj) + mcs * 4 * p.K;
+#pragma unroll
+            for (int m = 0; m < M_REP; ++m) wq[buf][m] = wj[m * wrep];
+            const int idx = mb + mj * p.d;
+            const bool ok = mv && idx >= 0 && idx < p.span;
+            const float t = xs[(mcs * 4 + kq) * p.XS + (ok ? idx : 0)];
+            xq[buf] = ok ? t : 0.f;
+            if (++mcs == csteps) { mcs = 0; ++mj; }
+          };
+          mload(0);
+          for (int it = 0; it < nit; it += 2) {
+            if (it + 1 < nit) mload(1);
+#pragma unroll
+            for (int m = 0; m < M_REP; ++m) tacc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq[0], wq[0][m], tacc[m], 0, 0, 0);
+            if (it + 1 < nit) {
+              if (it + 2 < nit) mload(0);
+#pragma unroll
+              for (int m = 0; m < M_REP; ++m) tacc[m] = __builtin_amdgcn_mfma_f32_16x16x4f32(xq[1], wq[1][m], tacc[m], 0, 0, 0);
+            }
+          }
+#pragma unroll
+          for (int m = 0; m < M_REP; ++m) acc[m][n] += tacc[m];
+        }
+      }
+    }
+    if (M_REP == 1 && (needL || needR)) {   // reflect-pad fold, 16-row tiles: plain loop (one MFMA per step, nothing to pipeline)
       for (int side = 0; side < 2; ++side) {
         if (side == 0 ? !needL : !needR) continue;
         int mb[N_REP]; bool mv[N_REP];
