@@ -316,3 +316,24 @@ def test_inference_path_long_utterance_vs_oracle(dev, tmp_path):
     with torch.no_grad():
         yo, _, _ = OM.generator(filled_sd('G'), x, c_tgt, exc.cpu())
     assert rel_l2(y, yo) < TOL
+
+
+@pytest.mark.parametrize('B,T', [(1, 8320), (3, 9600)], ids=['B1_Tmin8320', 'B3_T9600'])
+def test_generator_edge_sizes_vs_oracle(dev, B, T):
+    """Smallest legal utterance (T = 8320: 26 frames) with a single sample, and an odd batch at a length whose
+    per-stage sequence lengths are not multiples of the tile sizes (30 / 300 / 2400 / 4800 / 9600): forward outputs and the
+    content embedding against the CPU oracle, plus one backward pass for finiteness of every gradient."""
+    from oracle import model as OM
+    P = pkg()
+    G, _ = build_models(dev)
+    bt_cpu = P.synth.make_batch(B, T, seed=40 + B)
+    bt = to_dev(bt_cpu, dev)
+    with torch.no_grad():
+        yo, osubs, oemb = OM.generator(filled_sd('G'), bt_cpu['signal_real'], bt_cpu['c_tgt'], bt_cpu['c_f0_conv'])
+    G.arena.zero_grad()
+    y, subs = G(bt['signal_real'], bt['c_tgt'], c_var=bt['c_f0_conv'], out_subsample=True)
+    errs = dict(y=rel_l2(y, yo), sub4=rel_l2(subs[0], osubs[0]), sub2=rel_l2(subs[1], osubs[1]), emb=rel_l2(G.content_embedding, oemb))
+    assert max(errs.values()) < TOL, errs
+    (y.square().mean() + subs[0].square().mean() + subs[1].square().mean()).backward()
+    torch.cuda.synchronize()
+    assert all(torch.isfinite(p.grad).all() for p in G.parameters() if p.grad is not None)
