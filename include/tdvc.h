@@ -11,7 +11,10 @@
  *   - asynchronous on the hipStream_t passed as void* (NULL = default stream); no allocation, no
  *     synchronisation, no host read-back inside -> every call is hipGraph-capturable;
  *   - returns 0 (TDVC_OK) or a negative tdvc_status; never throws. tdvc_last_error() gives text;
- *   - re-entrant: no mutable globals.
+ *   - re-entrant: the compute entry points keep no mutable state (per-kernel LDS-size attributes are set under
+ *     std::call_once). The only process-global state is the TEST-ONLY switches tdvc_set_force_generic and
+ *     tdvc_debug_*: they exist so that the parity tests can reach and name every kernel instance; the product path
+ *     never calls them and they must not be flipped while another thread is launching.
  */
 #ifndef TDVC_H
 #define TDVC_H
@@ -103,8 +106,17 @@ int tdvc_conv_fwd(const tdvc_conv_desc* d, const tdvc_conv_fwd_args* a, void* st
 int tdvc_conv_dgrad(const tdvc_conv_desc* d, const tdvc_conv_dgrad_args* a, void* stream);
 int tdvc_conv_wgrad(const tdvc_conv_desc* d, const tdvc_conv_wgrad_args* a, void* stream);
 size_t tdvc_conv_wgrad_workspace(const tdvc_conv_desc* d);
-/* Force the scalar (non-MFMA) kernels: used by tests to cross-check the two code paths. */
+/* TEST-ONLY process-global switches (see the conventions above).
+ * tdvc_set_force_generic: route convs to the scalar (non-MFMA) kernels, to cross-check the two code paths.
+ * tdvc_debug_force_tile: pin the tile configuration of the lean stride-1 conv kernel (cfg 0..6 = <M_REP,N_REP,WM,WN> of
+ *   conv_lean.hip: 0 <1,4,1,4>, 1 <2,4,1,4>, 2 <4,4,1,4>, 3 <1,1,1,4>, 4 <1,4,4,1>, 5 <3,4,1,4>, 6 <1,2,2,2>; -1 = automatic,
+ *   grid-aware choice). Lets small test shapes run the instances that only large batches select.
+ * tdvc_debug_trace(1) clears and starts, (2) resumes, (0) stops recording the demangled names of the conv-family kernel
+ *   instantiations launched; tdvc_debug_trace_dump copies them ('\n'-separated, NUL-terminated) and returns the size needed. */
 void tdvc_set_force_generic(int on);
+void tdvc_debug_force_tile(int cfg);
+void tdvc_debug_trace(int on);
+size_t tdvc_debug_trace_dump(char* buf, size_t cap);
 
 /* Fused FiLM conditioning forward (model/generator.py:86-92, 103): gb = cond_var.2(LeakyReLU(cond_var.0(c))) with
  * c = [speaker embedding (n_cond-n_var channels, constant in time) ; excitation (n_var channels)]. The time-constant part

@@ -88,6 +88,16 @@ def grad_summary(named_grads, n_sample=4):
     return norms, samples
 
 
+def param_sample_idx(key, numel, n=64):
+    """Seeded element sample of one parameter tensor (shared with tests/test_model_gpu.py through oracle-free code:
+    the test re-derives the same indices from the key)."""
+    return np.random.RandomState(zlib.crc32(('upd:' + key).encode()) & 0x7FFFFFFF).randint(0, numel, size=min(n, numel))
+
+
+def feat_sample_idx(p_, m_, numel, n=48):
+    return np.random.RandomState(1000 + 10 * p_ + m_).randint(0, numel, size=min(n, numel))
+
+
 def feat_stats(f):
     f = f.detach().double()
     return [float(f.mean()), float(f.abs().mean()), float(f.std())]
@@ -183,9 +193,12 @@ def main():
         arrs.update({f'out_fake_{i}': o.detach().numpy() for i, o in enumerate(o_f)})
         arrs.update({f'sub_real_{i}': s.detach().numpy() for i, s in enumerate(rsubs)})
         np.savez_compressed(f'{OUT}/disc_{tag}.npz', **arrs)
+        fsamp = lambda fls: [[(f.detach().reshape(-1)[feat_sample_idx(p_, m_, f.numel())].tolist(), float(f.detach().double().pow(2).mean().sqrt()))
+                               for m_, f in enumerate(fl)] for p_, fl in enumerate(fls)]
         json.dump(dict(loss=float(dloss), norms=norms, samples=samples, noise=dnoise,
                        feat_stats_real=[[feat_stats(f) for f in fl] for fl in f_r],
-                       feat_stats_fake=[[feat_stats(f) for f in fl] for fl in f_f]),
+                       feat_stats_fake=[[feat_stats(f) for f in fl] for fl in f_f],
+                       feat_samples_real=fsamp(f_r), feat_samples_fake=fsamp(f_f)),
                   open(f'{OUT}/disc_{tag}.json', 'w'))
         # feature matching + contrastive from util/losses.py
         fm = RL.multiscale_feat_loss(f_f, f_r, norm_p=1)
@@ -239,8 +252,8 @@ def main():
     np.savez_compressed(f'{OUT}/latcls.npz', y=oc.detach().numpy(), dx=e.grad.numpy())
 
     # ---------------- full iterations: reference modules + torch AdamW vs oracle TrainStep
-    for cfg_name, T, B, iters in (('conv_enc-stage1', 8960, 2, 2), ('conv_enc-stage2_1', 8960, 2, 1),
-                                  ('conv_enc-stage1', 16000, 2, 1)):
+    for cfg_name, T, B, iters in (('conv_enc-stage1', 8960, 2, 2), ('conv_enc-stage2_1', 8960, 2, 2),
+                                  ('conv_enc-stage1', 16000, 2, 2), ('conv_enc-stage2_2', 8960, 2, 2)):
         import yaml
         docs = {}
         for d in yaml.safe_load_all(open(f'{REF}/config/{cfg_name}.yaml')):
@@ -268,6 +281,13 @@ def main():
             o_f, f_f = D(fake, bt['label_tgt'], fsubs)
             adv = sum(((o - 1) ** 2).mean() for o in o_f)
             _, f_real = D(bt['signal_real'], bt['label_src'], D.get_subsamples(bt['signal_real']))
+            l_rec = None
+            if not cfg.no_conv and cfg.lambda_rec > 0:      # train.py:344-361
+                rec, rsubs_ = G(fake.detach(), bt['c_src'], c_var=bt['c_f0_src'], out_subsample=True)
+                _, f_rec = D(rec, bt['label_src'], rsubs_)
+                l_rec_feat = RL.multiscale_feat_loss(f_rec, f_real, norm_p=1)
+                l_rec_spec = OL.log_mel_l1(rec, bt['signal_real'], cfg.fft_sizes)
+                l_rec = cfg.lambda_feat * l_rec_feat + cfg.lambda_spec * l_rec_spec
             if cfg.no_conv:
                 idt, isubs = fake, fsubs
             else:
@@ -280,11 +300,13 @@ def main():
             # same draws as the oracle: monkey-patch-free — use the oracle's contrastive with the
             # reference's tensors (its equivalence to util.losses.contrastive_loss is pinned above)
             l_con = OL.contrastive(emb_real, emb_cor, ix, iy)
-            g_loss = adv + cfg.lambda_idt * l_idt + cfg.lambda_cont_emb * l_con
+            g_loss = adv + (cfg.lambda_rec * l_rec if l_rec is not None else 0) + cfg.lambda_idt * l_idt + cfg.lambda_cont_emb * l_con
             opt_d.zero_grad(); opt_g.zero_grad(); g_loss.backward(); opt_g.step()
             ref_log = dict(D_loss_adv_real=float(l_r), D_loss_adv_fake=float(l_f), D_loss=float(l_r + l_f),
                            G_loss_adv_fake=float(adv), G_loss_idt_feat=float(l_feat), G_loss_idt_spec=float(l_spec),
                            G_loss_idt=float(l_idt), G_loss_cont_emb=float(l_con), G_loss=float(g_loss))
+            if l_rec is not None:
+                ref_log.update(G_loss_rec_feat=float(l_rec_feat), G_loss_rec_spec=float(l_rec_spec), G_loss_rec=float(l_rec))
             ora_log = ost.run(bt, ix, iy)
             pin[f'step_{cfg_name}_T{T}_it{it}'] = {k: abs(ora_log[k] - v) / (abs(v) + 1e-12) for k, v in ref_log.items()}
             log.append(ref_log)
@@ -298,6 +320,15 @@ def main():
         chk = lambda sd: {k: [float(v.double().sum()), float(v.double().abs().sum())] for k, v in sd.items()}
         json.dump(dict(config=cfg_name, B=B, T=T, iters=iters, losses=log, params_G=chk(G.state_dict()),
                        params_D=chk(D.state_dict())), open(f'{OUT}/step_{cfg_name}_T{T}.json', 'w'))
+        # sampled post-update parameter values (the UPDATE p_after - p_before is what a test can observe: an lr = 1e-4
+        # step moves sum|p| by ~1e-5 relative). Indices are seeded by the key; p_before is the deterministic fill.
+        upd = {}
+        for tag_, sd_after, sd_before in (('G', G.state_dict(), sd_g), ('D', D.state_dict(), sd_d)):
+            for k, v in sd_after.items():
+                idx = param_sample_idx(k, v.numel())
+                upd[f'{tag_}/{k}'] = v.detach().reshape(-1)[idx].numpy().astype(np.float32)
+                upd[f'{tag_}/{k}/dnorm'] = np.float64((v.detach().double() - sd_before[k].double()).norm())
+        np.savez_compressed(f'{OUT}/step_{cfg_name}_T{T}_update.npz', **upd)
 
     json.dump(pin, open(f'{OUT}/PINNING.json', 'w'), indent=1)
     print(json.dumps(pin, indent=1))

@@ -112,6 +112,19 @@ class TrainStep:
         if (c.lambda_rec > 0 or c.lambda_idt > 0) and c.lambda_feat > 0:
             with torch.no_grad():  # only used detached (Q6)
                 _, feats_real = M.discriminator(self.d, x, batch['label_src'], M.disc_subsamples(x))
+        if not c.no_conv and c.lambda_rec > 0:
+            # cycle reconstruction (train.py:344-361): the converted signal, detached, converted back to the source speaker
+            rec, rec_subs, _ = M.generator(self.g, fake.detach(), batch['c_src'], batch['c_f0_src'])
+            rec_loss = 0
+            if c.lambda_feat > 0:
+                _, feats_rec = M.discriminator(self.d, rec, batch['label_src'], rec_subs)
+                out['G_loss_rec_feat'] = L.feature_matching(feats_rec, feats_real)
+                rec_loss = rec_loss + c.lambda_feat * out['G_loss_rec_feat']
+            if c.lambda_spec > 0:
+                out['G_loss_rec_spec'] = L.log_mel_l1(rec, x, c.fft_sizes)
+                rec_loss = rec_loss + c.lambda_spec * out['G_loss_rec_spec']
+            out['G_loss_rec'] = rec_loss
+            total = total + c.lambda_rec * rec_loss
         if c.lambda_idt > 0:
             if c.no_conv:
                 idt, idt_subs, feats_idt_src = fake, fake_subs, None

@@ -78,6 +78,9 @@ SIGNATURES = {
     'tdvc_film_k3_bwd': (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp]),
     'tdvc_film_cond0_bwd_workspace': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     'tdvc_set_force_generic': (None, [_i]),
+    'tdvc_debug_force_tile': (None, [_i]),
+    'tdvc_debug_trace': (None, [_i]),
+    'tdvc_debug_trace_dump': (C.c_size_t, [C.c_char_p, C.c_size_t]),
     'tdvc_weight_norm_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'tdvc_weight_norm_fwd_t': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'tdvc_weight_norm_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
@@ -138,3 +141,31 @@ def lib():
 def check(rc):
     if rc != 0:
         raise TdvcError(f'tdvc call failed ({rc}): {lib().tdvc_last_error().decode()}')
+
+
+def traced_kernels():
+    """Names recorded since tdvc_debug_trace(1), normalised like rocprofv3's kernel names without spaces:
+    'conv_lean_kernel<1,4,1,4,0,0>'."""
+    l = lib()
+    n = l.tdvc_debug_trace_dump(None, 0)
+    buf = C.create_string_buffer(n)
+    l.tdvc_debug_trace_dump(buf, n)
+    return {normalize_kernel_name(s) for s in buf.value.decode().split('\n') if s}
+
+
+def normalize_kernel_name(s):
+    """'void tdvc::conv_lean_kernel<3, 4, 1, 4, 0, 1>(tdvc::LeanP)' -> 'conv_lean_kernel<3,4,1,4,0,1>'."""
+    s = s.strip().strip('"').replace('(anonymous namespace)::', '')
+    if s.startswith('void '):
+        s = s[5:]
+    depth, cut = 0, len(s)
+    for i, ch in enumerate(s):      # drop the argument list: first '(' outside template brackets
+        if ch == '<':
+            depth += 1
+        elif ch == '>':
+            depth -= 1
+        elif ch == '(' and depth == 0:
+            cut = i
+            break
+    s = s[:cut].replace(' ', '').replace('tdvc::', '').replace('(anonymousnamespace)::', '')
+    return s

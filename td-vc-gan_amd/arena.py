@@ -9,7 +9,14 @@ gradient all-reduce is a handful of large RCCL calls over `G`, and zero_grad is 
 Parameters the forward never reads (`decoder.excite_downsample.0.*`) sit at the tail of
 the arena, outside the live prefix: their .grad stays None and AdamW skips them, exactly like
 torch.optim.AdamW skips grad-less parameters in the reference (train.py:188, Q7).
+
+Data-parallel runs (parallel.GradSync) additionally use the arena's SEGMENTS: the live prefix is cut into contiguous
+pieces of ~8 MiB aligned to layer boundaries. Every weight-gradient launch reports its layer (note_grad); once all the
+contributions a segment receives in one backward pass have been launched, the segment's weight-norm fold runs and its
+slice of `G` is handed to the RCCL all-reduce on a side stream while the backward pass continues (SURVEY §8e schedule).
 """
+import bisect
+
 import torch
 
 from . import _lib as L
@@ -17,14 +24,65 @@ from . import _lib as L
 
 class ConvSlot:
     """Raw device addresses of one conv layer's tensors inside the arenas."""
-    __slots__ = ('w', 'b', 'dw', 'db', 'trainable', 'arena', 'wt')
+    __slots__ = ('w', 'b', 'dw', 'db', 'trainable', 'arena', 'wt', 'seg')
 
-    def __init__(self, w=0, b=0, dw=0, db=0, trainable=True, arena=None, wt=0):
+    def __init__(self, w=0, b=0, dw=0, db=0, trainable=True, arena=None, wt=0, seg=-1):
         self.w, self.b, self.dw, self.db, self.trainable, self.arena, self.wt = w, b, dw, db, trainable, arena, wt
+        self.seg = seg          # arena segment holding this layer's parameters (gradient bucketing, -1 = none)
+
+
+def plan_segments(keys, offsets, n_live, target):
+    """Cut [0, n_live) into contiguous segments of >= `target` elements whose boundaries fall between layers (a layer =
+    the parameters sharing one prefix: bias, weight_g, weight_v). Returns the nseg + 1 boundary offsets."""
+    bounds, prev = [0], None
+    for k in keys:
+        prefix = k.rsplit('.', 1)[0]
+        o = offsets[k]
+        if prefix != prev and o - bounds[-1] >= target:
+            bounds.append(o)
+        prev = prefix
+    if n_live - bounds[-1] < target // 4 and len(bounds) > 1:      # fold a short tail into the previous segment
+        bounds.pop()
+    bounds.append(n_live)
+    return bounds
+
+
+class SegmentTracker:
+    """Host-side bookkeeping of which gradient segments are complete during a backward pass (no device work here, so
+    the logic is covered by the CPU tests). The number of contributions each segment receives per pass is learned on
+    the first pass after attach (that pass reduces everything at its end) and re-checked on every later pass."""
+
+    def __init__(self, nseg):
+        self.nseg = nseg
+        self.expected = None
+        self.begin()
+
+    def begin(self):
+        self.seen = [0] * self.nseg
+        self.fired = [False] * self.nseg
+
+    def note(self, seg):
+        """A weight-gradient launch for a layer of `seg` was just queued. Returns True when the segment is complete."""
+        if self.fired[seg]:
+            raise RuntimeError(f'gradient contribution for arena segment {seg} after the segment was handed to the all-reduce '
+                               '(the backward graph changed: call ParamArena.reset_segment_profile())')
+        self.seen[seg] += 1
+        if self.expected is not None and self.seen[seg] == self.expected[seg]:
+            self.fired[seg] = True
+            return True
+        return False
+
+    def finish(self):
+        """End of the pass: the segments not yet handed over (all of them on the learning pass). Updates the profile."""
+        rest = [i for i in range(self.nseg) if not self.fired[i]]
+        self.expected = list(self.seen)
+        for i in rest:
+            self.fired[i] = True
+        return rest
 
 
 class ParamArena:
-    def __init__(self, module: torch.nn.Module, device, dead_prefixes=(), transposable=()):
+    def __init__(self, module: torch.nn.Module, device, dead_prefixes=(), transposable=(), seg_bytes=8 << 20):
         """transposable: prefixes of weight-normed stride-1, groups==1 convs whose effective weight is also kept
         pre-transposed as [Cin][Cout][K] (arena WT) for the input-gradient kernel."""
         named = list(module.named_parameters())
@@ -85,6 +143,19 @@ class ParamArena:
         self.token = torch.zeros(1, dtype=torch.float32, device=self.device, requires_grad=True)
         self._grads_attached = False
         self._finish_queued = False
+        # gradient segments (data-parallel bucketing): boundaries in P/G offsets and the weight-norm rows of each
+        self.seg_bounds = plan_segments(self.live_keys, self.offsets, self.n_live, max(1, seg_bytes // 4))
+        self.nseg = len(self.seg_bounds) - 1
+        self.seg_rows = []
+        r = 0
+        for i in range(self.nseg):
+            r0 = r
+            for pre, vo, _, _, rows, _ in self.wn:
+                if self.seg_bounds[i] <= vo < self.seg_bounds[i + 1]:
+                    r += rows
+            self.seg_rows.append((r0, r))
+        self._sync = None          # parallel.GradSync when attached
+        self._track = None
 
     # ------------------------------------------------------------------ addresses
     def slot(self, prefix: str, has_bias: bool) -> ConvSlot:
@@ -101,7 +172,11 @@ class ParamArena:
             o = self.offsets[prefix + '.bias']
             b, db = pb + 4 * o, gb + 4 * o
         wt = self.WT.data_ptr() + 4 * self.w_offsets[prefix] if prefix in self.transposed else 0
-        return ConvSlot(w, b, dw, db, True, self, wt)
+        first = self.offsets[prefix + ('.weight_v' if prefix in self.w_offsets else '.weight')]
+        return ConvSlot(w, b, dw, db, True, self, wt, self.seg_of(first))
+
+    def seg_of(self, offset: int) -> int:
+        return max(0, min(self.nseg - 1, bisect.bisect_right(self.seg_bounds, offset) - 1))
 
     def owns(self, p: torch.Tensor) -> bool:
         a = p.data_ptr()
@@ -124,15 +199,45 @@ class ParamArena:
         for p in self.params.values():
             p.grad = None
         self._grads_attached = False
+        if self._track is not None:
+            self._track.begin()
+
+    # ------------------------------------------------------------------ data-parallel gradient segments
+    def attach_sync(self, sync):
+        """Hand completed gradient segments to `sync.reduce_segment(arena, seg)` as the backward pass produces them."""
+        self._sync = sync
+        self._track = SegmentTracker(self.nseg) if sync is not None else None
+
+    def reset_segment_profile(self):
+        if self._track is not None:
+            self._track = SegmentTracker(self.nseg)
+
+    def _fold_rows(self, r0, r1):
+        """(v, g) gradients of weight-norm rows [r0, r1) from the effective-weight gradients in dW."""
+        if r1 > r0:
+            st = torch.cuda.current_stream(self.device).cuda_stream
+            L.check(L.lib().tdvc_weight_norm_bwd(self.P.data_ptr(), self.dW.data_ptr(), self.G.data_ptr(),
+                                                 self.row_voff.data_ptr() + 8 * r0, self.row_goff.data_ptr() + 8 * r0,
+                                                 self.row_woff.data_ptr() + 8 * r0, self.row_len.data_ptr() + 4 * r0, r1 - r0, 0, st))
+
+    def _segment_ready(self, seg):
+        self._fold_rows(*self.seg_rows[seg])
+        self._sync.reduce_segment(self, seg)
+
+    def note_grad(self, slot):
+        """Called by the operators right after a weight-gradient launch of `slot`'s layer was queued."""
+        self.queue_finish()
+        if self._track is not None and slot.seg >= 0 and self._track.note(slot.seg):
+            self._segment_ready(slot.seg)
 
     def finish_grads(self):
         """Fold the effective-weight gradients into (v, g) gradients and expose .grad views."""
         self._finish_queued = False
-        if self.nrows:
-            st = torch.cuda.current_stream(self.device).cuda_stream
-            L.check(L.lib().tdvc_weight_norm_bwd(self.P.data_ptr(), self.dW.data_ptr(), self.G.data_ptr(),
-                                                 self.row_voff.data_ptr(), self.row_goff.data_ptr(),
-                                                 self.row_woff.data_ptr(), self.row_len.data_ptr(), self.nrows, 0, st))
+        if self._track is not None:
+            for seg in self._track.finish():
+                self._segment_ready(seg)
+        elif self.nrows:
+            self._fold_rows(0, self.nrows)
         if not self._grads_attached:
             for k in self.live_keys:
                 p = self.params[k]

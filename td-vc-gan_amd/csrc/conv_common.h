@@ -11,6 +11,22 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <mutex>
+
+// Host-side launch helpers. TDVC_BIG_LDS_ONCE: raise the dynamic-LDS cap of one kernel instantiation exactly once
+// (thread-safe: the C ABI is re-entrant). TDVC_TRACE: test-only record of which kernel instantiation a launch used
+// (tdvc_debug_trace in include/tdvc.h; a single predictable branch when tracing is off).
+#define TDVC_BIG_LDS_ONCE(k)                                                                                         \
+  do {                                                                                                               \
+    static std::once_flag f_;                                                                                        \
+    std::call_once(f_, [&] { hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); }); \
+  } while (0)
+namespace tdvc {
+extern int g_trace_on;
+extern int g_force_tile;
+void trace_kernel(const void* fn);
+}
+#define TDVC_TRACE(k) do { if (tdvc::g_trace_on) tdvc::trace_kernel(reinterpret_cast<const void*>(k)); } while (0)
 
 namespace tdvc {
 

@@ -497,16 +497,11 @@ static inline void walk_geometry(int rows, int nvec, int* rp, int* np) {
   *np = *rp ? (rows + *rp - 1) / *rp : 1 << 20;
 }
 
-template <typename K> static inline void lean_big_lds(K k) {
-  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-}
-
 template <int M_REP, int N_REP, int WM, int WN, int XFK, int EPI>
 static hipError_t lean_launch3(const LeanP& p, int B, hipStream_t st) {
   constexpr int MT = 16 * M_REP * WM, NT = 16 * N_REP * WN;
   auto k = conv_lean_kernel<M_REP, N_REP, WM, WN, XFK, EPI>;
-  static bool once = false;
-  if (!once) { lean_big_lds(k); once = true; }
+  TDVC_BIG_LDS_ONCE(k); TDVC_TRACE(k);
   dim3 grid((p.T + NT - 1) / NT, (p.Cout + MT - 1) / MT, B);
   const size_t lds = (size_t)(p.xnp * p.xrp * p.XS + p.wnp * p.wrp * p.WS) * sizeof(float);
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
@@ -549,13 +544,11 @@ hipError_t launch_conv_lean_cond(LeanP p, int B, hipStream_t st) {
   dim3 grid((p.T + NT - 1) / NT, (p.Cout + MT - 1) / MT, B);
   if (MT == 32) {
     auto k = conv_lean_kernel<2, 4, 1, 4, LXF_COND, EPI_FWD>;
-    static bool once = false;
-    if (!once) { lean_big_lds(k); once = true; }
+    TDVC_BIG_LDS_ONCE(k); TDVC_TRACE(k);
     hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
   } else {
     auto k = conv_lean_kernel<4, 4, 1, 4, LXF_COND, EPI_FWD>;
-    static bool once = false;
-    if (!once) { lean_big_lds(k); once = true; }
+    TDVC_BIG_LDS_ONCE(k); TDVC_TRACE(k);
     hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
   }
   return hipGetLastError();
@@ -579,6 +572,10 @@ hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st) {
     const long blocks = (long)((R + c.MT - 1) / c.MT) * ((p.T + c.NT - 1) / c.NT) * B;
     MT = c.MT; NT = c.NT; cfg = c.cfg;
     if (blocks >= 512) break;
+  }
+  if (g_force_tile >= 0) {   // test-only (tdvc_debug_force_tile): pin the tile so that small shapes reach every instance
+    for (const Cand& c : cands)
+      if (c.cfg == g_force_tile) { MT = c.MT; NT = c.NT; cfg = c.cfg; }
   }
   const int first = -p.pad;
   int lo = -p.pad - p.mirror;

@@ -477,17 +477,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_scalar_kernel(const WgradP p, 
 // host-side launchers (called from conv_api.cpp)
 namespace tdvc {
 
-template <typename KernelT>
-static inline void allow_big_lds(KernelT k) {
-  hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);
-}
-
 template <int MODE, int M_REP, int N_REP, int WM, int WN, bool PIPE>
 static hipError_t launch_gemm_cfg2(const GemmConvP& p, int B, hipStream_t st) {
   constexpr int MT = 16 * M_REP * WM, NT = 16 * N_REP * WN;
   auto k = conv_gemm_kernel<MODE, M_REP, N_REP, WM, WN, PIPE>;
-  static bool once = false;
-  if (!once) { allow_big_lds(k); once = true; }
+  TDVC_BIG_LDS_ONCE(k); TDVC_TRACE(k);
   dim3 grid((p.N + NT - 1) / NT, p.groups * ((p.R + MT - 1) / MT), B);
   size_t lds = (size_t)(p.Cc * p.XS + MT * p.WS) * sizeof(float);
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
@@ -556,6 +550,7 @@ hipError_t launch_conv_scalar(GemmConvP p, int B, hipStream_t st) {
   p.lo = 0; p.span = 0;
   long total = (long)p.N * p.R;
   int gx = (int)((total + 255) / 256); if (gx > 4096) gx = 4096; if (gx < 1) gx = 1;
+  TDVC_TRACE(conv_scalar_kernel<MODE>);
   hipLaunchKernelGGL(conv_scalar_kernel<MODE>, dim3(gx, p.groups, B), dim3(256), 0, st, p);
   return hipGetLastError();
 }
@@ -571,8 +566,7 @@ template <int MODE, int M_REP, int J>
 static hipError_t launch_wgrad_cfg(WgradP& p, int B, int bpb, hipStream_t st) {
   constexpr int MT = 16 * M_REP;
   auto k = conv_wgrad_kernel<MODE, M_REP, J>;
-  static bool once = false;
-  if (!once) { allow_big_lds(k); once = true; }
+  TDVC_BIG_LDS_ONCE(k); TDVC_TRACE(k);
   const int mtiles = (p.R + MT - 1) / MT, ctiles = (p.Cred + 15) / 16;
   const int nbg = (B + bpb - 1) / bpb;
   dim3 grid(nbg * p.ntiles, p.groups * mtiles * ctiles, 1);
@@ -639,6 +633,7 @@ template hipError_t launch_conv_wgrad<MODE_DOWN>(WgradP, int, int, hipStream_t);
 
 template <int MODE>
 hipError_t launch_conv_wgrad_scalar(WgradP p, int B, long nweights, float* dw, hipStream_t st) {
+  TDVC_TRACE(conv_wgrad_scalar_kernel<MODE>);
   hipLaunchKernelGGL(conv_wgrad_scalar_kernel<MODE>, dim3((unsigned)nweights), dim3(256), 0, st, p, B, dw);
   return hipGetLastError();
 }

@@ -323,8 +323,7 @@ template <int M_REP, int C_REP, int J, int D, bool SCAL>
 static hipError_t wt_launch2(const WgLeanP& p, int B, hipStream_t st) {
   constexpr int MT = 32 * M_REP, CT = 32 * C_REP;
   auto k = conv_wgrad_tile_kernel<M_REP, C_REP, J, D, SCAL>;
-  static bool once = false;
-  if (!once) { hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  TDVC_BIG_LDS_ONCE(k); TDVC_TRACE(k);
   dim3 grid(p.ngroups, ((p.R + MT - 1) / MT) * ((p.Cin + CT - 1) / CT), 1);      // wide: ngroups counts (sample, tile) chunk groups
   const size_t lds = (size_t)(MT * WT_AS + CT * WT_XS) * sizeof(float);
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
@@ -335,8 +334,7 @@ template <int M_REP, int C_REP, int J, int D>
 static hipError_t wg_launch(const WgLeanP& p, int B, hipStream_t st) {
   constexpr int MT = 16 * M_REP, CT = 16 * C_REP;
   auto k = conv_wgrad_lean_kernel<M_REP, C_REP, J, D>;
-  static bool once = false;
-  if (!once) { hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  TDVC_BIG_LDS_ONCE(k); TDVC_TRACE(k);
   dim3 grid(B * p.ngroups, ((p.R + MT - 1) / MT) * ((p.Cin + CT - 1) / CT), 1);
   size_t lds = (size_t)(MT * WG_AS + CT * WG_XS) * sizeof(float);
   const size_t red = (size_t)M_REP * C_REP * J * 4 * 64 * sizeof(float);

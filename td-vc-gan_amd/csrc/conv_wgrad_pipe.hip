@@ -275,8 +275,7 @@ template <int M_REP, int C_REP, int J, int D, bool XFILM>
 static hipError_t wp_launch2(const WgLeanP& p, hipStream_t st) {
   constexpr int MT = 32 * M_REP, CT = 32 * C_REP, XSW = WpGeom<J, D>::XSW;
   auto k = conv_wgrad_pipe_kernel<M_REP, C_REP, J, D, XFILM>;
-  static bool once = false;
-  if (!once) { hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  TDVC_BIG_LDS_ONCE(k); TDVC_TRACE(k);
   if (p.span + 2 > XSW || p.xnp > (XFILM ? 4 : 4 * C_REP)) return hipErrorNotSupported;
   dim3 grid(p.ngroups, ((p.R + MT - 1) / MT) * ((p.Cin + CT - 1) / CT), 1);
   const size_t lds = (size_t)2 * (MT * WP_AS + CT * XSW) * sizeof(float);

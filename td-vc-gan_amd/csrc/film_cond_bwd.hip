@@ -321,8 +321,7 @@ extern "C" int tdvc_film_cond0_bwd(const tdvc_film_cond0_bwd_args* a, void* stre
   }
   if (hipMemsetAsync(a->dk3, 0, (size_t)a->B * a->n_cond * 3 * sizeof(float), st) != hipSuccess)
     return tdvc_fail(TDVC_ELAUNCH, "film_cond0_bwd: memset failed");
-  static bool once = false;
-  if (!once) { hipFuncSetAttribute(reinterpret_cast<const void*>(film_cond0_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  TDVC_BIG_LDS_ONCE(film_cond0_bwd_kernel); TDVC_TRACE(film_cond0_bwd_kernel);
   const size_t lds = (size_t)(CB_ROWS * CB_S + 8 * CB_S + CB_ROWS * CB_WS + 4 * CB_ROWS * 3) * sizeof(float);
   hipLaunchKernelGGL(film_cond0_bwd_kernel, dim3(nblocks), dim3(256), lds, st, p);
   TDVC_CHECK_LAUNCH();

@@ -4,7 +4,10 @@
 // All are HBM-bound streaming / reduction kernels: coalesced along T, wave64 shuffle reductions.
 #include "../../include/tdvc.h"
 #include "api_util.h"
+#include "conv_common.h"
 #include <math.h>
+#include <stdlib.h>
+#include <string.h>
 
 static thread_local char g_err[256] = "";
 int tdvc_fail(int code, const char* msg) {
@@ -12,7 +15,49 @@ int tdvc_fail(int code, const char* msg) {
   return code;
 }
 extern "C" const char* tdvc_last_error(void) { return g_err; }
-extern "C" int tdvc_version(void) { return 100; }
+extern "C" int tdvc_version(void) { return 200; }
+
+// ------------------------------------------------------------------------------ test-only debug hooks
+// Process-global switches used by the parity tests to (a) pin the tile configuration of the lean conv kernel so that
+// every template instance the train step can select is checked against the float64 reference at small shapes, and
+// (b) record which kernel instantiations the launches of a test actually used. Never touched by the product path.
+#include <cxxabi.h>
+#include <mutex>
+#include <set>
+#include <string>
+namespace tdvc {
+int g_trace_on = 0;
+int g_force_tile = -1;
+static std::mutex g_trace_mu;
+static std::set<std::string> g_trace_names;
+void trace_kernel(const void* fn) {
+  const char* mangled = hipKernelNameRefByPtr(fn, nullptr);
+  std::string name;
+  if (mangled) {
+    int status = 0;
+    char* dem = abi::__cxa_demangle(mangled, nullptr, nullptr, &status);
+    name = (status == 0 && dem) ? dem : mangled;
+    free(dem);
+  } else {
+    char buf[32]; snprintf(buf, sizeof(buf), "kernel@%p", fn); name = buf;
+  }
+  std::lock_guard<std::mutex> lk(g_trace_mu);
+  g_trace_names.insert(name);
+}
+}  // namespace tdvc
+extern "C" void tdvc_debug_force_tile(int cfg) { tdvc::g_force_tile = cfg; }
+extern "C" void tdvc_debug_trace(int on) {
+  std::lock_guard<std::mutex> lk(tdvc::g_trace_mu);
+  if (on == 1) tdvc::g_trace_names.clear();
+  tdvc::g_trace_on = on ? 1 : 0;
+}
+extern "C" size_t tdvc_debug_trace_dump(char* buf, size_t cap) {
+  std::lock_guard<std::mutex> lk(tdvc::g_trace_mu);
+  std::string all;
+  for (const std::string& n : tdvc::g_trace_names) { all += n; all += '\n'; }
+  if (buf && cap) { const size_t n = all.size() < cap - 1 ? all.size() : cap - 1; memcpy(buf, all.data(), n); buf[n] = 0; }
+  return all.size() + 1;
+}
 
 namespace {
 
@@ -620,8 +665,7 @@ extern "C" int tdvc_contrastive_fwd_bwd(const float* X, const float* Y, const in
   if (C <= 0 || T <= 1 || N <= 0) return tdvc_fail(TDVC_EINVAL, "contrastive: bad shape");
   const size_t lds = (size_t)(C * T + T + 2 * (N + 1) + 2 * C + 8) * sizeof(float);
   if (lds > 150 * 1024) return tdvc_fail(TDVC_EUNSUPPORTED, "contrastive: embedding tile exceeds LDS");
-  static bool once = false;
-  if (!once) { hipFuncSetAttribute(reinterpret_cast<const void*>(contrastive_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024); once = true; }
+  TDVC_BIG_LDS_ONCE(contrastive_kernel);
   const float coef = weight / (2.f * (float)B * (float)T);
   const int tsplit = T < 16 ? T : 16;            // 2 * B * 16 blocks instead of 2 * B serial walks over T
   hipLaunchKernelGGL(contrastive_kernel, dim3(2, B, tsplit), dim3(128), lds, (hipStream_t)stream, X, Y, idx_x, idx_y, C, T, N, coef, loss_out, dX, dY);

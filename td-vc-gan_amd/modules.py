@@ -178,7 +178,7 @@ class FiLMResnetBlock(nn.Module):
         if self.has_cond and self.cond_var[0].spec.slot is not None:
             s = self.cond_var[0].spec.slot
             self.spec_const.slot = s                                             # carries the bias
-            self.spec_var.slot = ConvSlot(s.w, 0, s.dw, 0, s.trainable, s.arena, s.wt)  # no bias on the time-varying part
+            self.spec_var.slot = ConvSlot(s.w, 0, s.dw, 0, s.trainable, s.arena, s.wt, s.seg)  # no bias on the time-varying part
 
     def forward(self, x, c=None, acc=None, scale=1.0):
         """c: None (encoder), a dense [B,n_const+n_var,T] conditioning tensor (reference formulation), or a

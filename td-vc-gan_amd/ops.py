@@ -122,7 +122,7 @@ def conv_wgrad_raw(spec: ConvSpec, x, x_xf, dy, dy_xf):
                         ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0)
     L.check(lib.tdvc_conv_wgrad(C.byref(d), C.byref(a), _stream(x)))
     if s.arena is not None:
-        s.arena.queue_finish()
+        s.arena.note_grad(s)
 
 
 PRE_NONE, PRE_LRELU = 0, 1
@@ -275,7 +275,7 @@ class FilmCondFn(Function):
                                ws.data_ptr() if ws is not None else None, ws.numel() * ws.element_size() if ws is not None else 0)
         L.check(lib.tdvc_film_cond0_bwd(C.byref(a), _stream(dgb)))
         if want_w and sv.arena is not None:
-            sv.arena.queue_finish()
+            sv.arena.note_grad(sv)
         return dexc, dk3, None, None, None
 
 
@@ -306,7 +306,7 @@ class FilmK3Fn(Function):
         L.check(L.lib().tdvc_film_k3_bwd(dk3.data_ptr(), emb.data_ptr(), emb.stride(0), s.w, demb.data_ptr() if demb is not None else None,
                                          s.dw if want_w else None, (s.db or None) if want_w else None, B, n_const, ctx.spec.cout, _stream(dk3)))
         if want_w and s.arena is not None:
-            s.arena.queue_finish()
+            s.arena.note_grad(s)
         return demb, None, None
 
 

@@ -1,7 +1,8 @@
 """One TD-VC-GAN training iteration (D-step + G-step, both AdamW updates) on the HIP path.
 
 Mirrors the loop body of the reference's train.py:209-521 (D-step :259-316, G-step :320-510,
-loss assembly :477-482, optimizers :188-189) for the configuration space of the shipped YAMLs,
+loss assembly :477-482, optimizers :188-189; cycle-reconstruction branch :344-361 when lambda_rec > 0)
+for the configuration space of the shipped YAMLs,
 minus the CREPE-backed F0 term (:429-470, torchcrepe unavailable: SURVEY §8c) and minus work
 that reaches no parameter update:
   Q3  the D-step's generator forward runs without a graph (the reference back-propagates into G
@@ -41,7 +42,28 @@ class StepConfig:
 
     @staticmethod
     def from_hparams(train: dict) -> 'StepConfig':
+        """Build from the `train` document of a reference YAML (config/*.yaml). Keys that change what is optimised and
+        that this path does not implement raise instead of being dropped silently; `lambda_f0` (the CREPE-backed F0 term,
+        train.py:429-470) is excluded by contract (torchcrepe is not available: SURVEY §8c) and only warns."""
         g = train.get
+        unsupported = {
+            'lambda_wave': (g('lambda_wave', 0) or 0) != 0,              # train.py:357-360, 381-384
+            'lambda_converted': bool(g('lambda_converted', 0)),          # train.py:409-413
+            'jitter_amp': (g('jitter_amp', 0) or 0) > 0,                 # train.py:335-336
+            'grad_max_norm_D': g('grad_max_norm_D') is not None,         # train.py:289-290
+            'grad_max_norm_G': g('grad_max_norm_G') is not None,         # train.py:489-490
+            'D_step_interval': (g('D_step_interval', 1) or 1) != 1,      # train.py:259
+            'G_step_interval': (g('G_step_interval', 1) or 1) != 1,      # train.py:320
+            'freeze_subnets': bool(g('freeze_subnets')),                 # train.py:195-197
+        }
+        bad = [k for k, v in unsupported.items() if v]
+        if bad:
+            raise NotImplementedError(f'train config keys not implemented on the HIP path: {bad} '
+                                      '(they change the objective / schedule; refusing to train something else silently)')
+        if float(g('lambda_f0', 0) or 0) != 0:
+            import warnings
+            warnings.warn('lambda_f0 != 0: the CREPE-backed F0 loss term (train.py:429-470) is not part of this path '
+                          '(torchcrepe unavailable); the iteration runs without it', stacklevel=2)
         return StepConfig(no_conv=bool(g('no_conv', False)), lambda_rec=float(g('lambda_rec', 0)),
                           lambda_idt=float(g('lambda_idt', 0)), lambda_feat=float(g('lambda_feat', 0)),
                           lambda_spec=float(g('lambda_spec', 0)), lambda_cont_emb=float(g('lambda_cont_emb', 0)),
@@ -53,8 +75,6 @@ class StepConfig:
 
 class TrainStep:
     def __init__(self, G, D, cfg: StepConfig, device, reuse_fake=True, grad_sync=None, C=None):
-        if cfg.lambda_rec > 0:
-            raise NotImplementedError('lambda_rec > 0 (cycle reconstruction branch, train.py:344-361) is not built yet')
         self.G, self.D, self.cfg, self.device = G, D, cfg, torch.device(device)
         self.reuse_fake = reuse_fake
         self.grad_sync = grad_sync            # parallel.GradSync or None
@@ -63,6 +83,8 @@ class TrainStep:
         self.opt_d = FlatAdamW(da, cfg.lr_d, cfg.betas, cfg.eps, cfg.weight_decay)
         G.weights_frozen(True); D.weights_frozen(True)     # effective weights are rebuilt right after each update
         ga.materialize(); da.materialize()
+        if grad_sync is not None:     # completed gradient segments go to the all-reduce while backward continues
+            grad_sync.attach(ga); grad_sync.attach(da)
         # latent classifier (train.py:153-154; optimizer :192 is torch.optim.Adam(lr_d, adam_beta): no weight decay)
         self.C = None
         if cfg.lambda_latcls != 0:
@@ -73,6 +95,8 @@ class TrainStep:
             self.opt_c = FlatAdamW(ca, cfg.lr_d, cfg.betas, cfg.eps, 0.0)
             C.weights_frozen(True)
             ca.materialize()
+            if grad_sync is not None:
+                grad_sync.attach(ca)
 
     # -------------------------------------------------------------------------------------------
     def _generate(self, batch):
@@ -91,9 +115,9 @@ class TrainStep:
         return fake, idt, emb_real, emb_cor
 
     def d_step(self, batch, log):
-        self._d_fwd_bwd(batch, log)
+        self._d_fwd_bwd(batch, log)       # data-parallel: segment all-reduces were issued during / at the end of backward
         if self.grad_sync is not None:
-            self.grad_sync.all_reduce(self.D.arena)
+            self.grad_sync.wait(self.D.arena)
         self._d_update()
 
     def _d_update(self):
@@ -128,7 +152,7 @@ class TrainStep:
     def g_step(self, batch, log, idx_x=None, idx_y=None):
         self._g_fwd_bwd(batch, log, idx_x, idx_y)
         if self.grad_sync is not None:
-            self.grad_sync.all_reduce(self.G.arena)
+            self.grad_sync.wait(self.G.arena)
         self._g_update()
 
     def _g_update(self):
@@ -150,12 +174,34 @@ class TrainStep:
                 (fake, fake_subs), idt_pair, emb_real, emb_cor = self._generate(batch)
             need_feat = c.lambda_idt > 0 and c.lambda_feat > 0
             separate_idt = need_feat and idt_pair is not None and idt_pair[0] is not fake
-            if separate_idt:    # fake and identity signals through D in one call (batch 2B)
-                idt, idt_subs = idt_pair
-                outs, feats = D(torch.cat([fake, idt], dim=0), torch.cat([batch['label_tgt'], batch['label_src']], dim=0),
-                                [torch.cat([a, b_], dim=0) for a, b_ in zip(fake_subs, idt_subs)])
+            want_rec = c.lambda_rec > 0 and not c.no_conv
+            rec = rec_subs = feats_rec = None
+            if want_rec:
+                # cycle reconstruction (train.py:344-361): G(fake.detach(), c_src, c_var=c_f0_src) -- a second, sequentially
+                # dependent generator pass; its encoder sees the converted signal, its decoder the source conditioning
+                from .modules import generator_forward_pair
+                (rec_pair,), _, _ = generator_forward_pair(G, fake.detach(), None, [batch['c_src']], [batch['c_f0_src']])
+                rec, rec_subs = rec_pair
+            if separate_idt or (want_rec and c.lambda_feat > 0):
+                # fake, identity and reconstructed signals through D in ONE call (batch 2B / 3B): exact, D has no cross-sample op
+                sigs, subs, labels = [fake], [fake_subs], [batch['label_tgt']]
+                if separate_idt:
+                    sigs.append(idt_pair[0]); subs.append(idt_pair[1]); labels.append(batch['label_src'])
+                if want_rec and c.lambda_feat > 0:
+                    sigs.append(rec); subs.append(rec_subs); labels.append(batch['label_src'])
+                outs, feats = D(torch.cat(sigs, dim=0), torch.cat(labels, dim=0),
+                                [torch.cat([s_[i] for s_ in subs], dim=0) for i in range(len(fake_subs))])
                 out_fake = [o[:B] for o in outs]
-                feats_idt = [[m[B:] for m in fl] for fl in feats]
+                feats_fake = [[m[:B] for m in fl] for fl in feats]
+                pos = 1
+                idt, idt_subs = (fake, fake_subs) if idt_pair is not None else (None, None)
+                feats_idt = None
+                if separate_idt:
+                    idt, idt_subs = idt_pair
+                    feats_idt = [[m[pos * B:(pos + 1) * B] for m in fl] for fl in feats]
+                    pos += 1
+                if want_rec and c.lambda_feat > 0:
+                    feats_rec = [[m[pos * B:(pos + 1) * B] for m in fl] for fl in feats]
             else:
                 out_fake, feats_fake = D(fake, batch['label_tgt'], fake_subs)
                 idt, idt_subs = (fake, fake_subs) if idt_pair is not None else (None, None)
@@ -170,11 +216,26 @@ class TrainStep:
             adv = LS.lsgan_loss(out_fake, 1.0)
             total = adv
             log['G_loss_adv_fake'] = adv.detach()
+            feats_real = None
+            if (need_feat and idt is not None) or feats_rec is not None:
+                with torch.no_grad():                      # Q6: D(real) feature maps are only ever used detached
+                    _, feats_real = D(real, batch['label_src'], self._real_subs)
+            if want_rec:                                   # train.py:344-361
+                l_rec = None
+                if feats_rec is not None:
+                    l_rf = LS.multiscale_feat_loss(feats_rec, feats_real, norm_p=1)
+                    log['G_loss_rec_feat'] = l_rf.detach()
+                    l_rec = c.lambda_feat * l_rf
+                if c.lambda_spec > 0:
+                    l_rs = LS.multiscale_spec_loss(rec, real, list(c.fft_sizes))
+                    log['G_loss_rec_spec'] = l_rs.detach()
+                    l_rec = c.lambda_spec * l_rs if l_rec is None else l_rec + c.lambda_spec * l_rs
+                if l_rec is not None:
+                    log['G_loss_rec'] = l_rec.detach()
+                    total = total + c.lambda_rec * l_rec
             if c.lambda_idt > 0 and idt is not None:
                 l_idt = None
                 if need_feat:
-                    with torch.no_grad():                  # Q6
-                        _, feats_real = D(real, batch['label_src'], self._real_subs)
                     l_feat = LS.multiscale_feat_loss(feats_idt, feats_real, norm_p=1)
                     log['G_loss_idt_feat'] = l_feat.detach()
                     l_idt = c.lambda_feat * l_feat
@@ -220,7 +281,7 @@ class TrainStep:
         self.opt_c.zero_grad()
         c_loss.backward()
         if self.grad_sync is not None:
-            self.grad_sync.all_reduce(C.arena)
+            self.grad_sync.wait(C.arena)
         self.opt_c.step(grad_scale=1.0 if self.grad_sync is None else self.grad_sync.scale)
         C.arena.materialize()
         log['C_loss'] = c_loss.detach()

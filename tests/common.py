@@ -62,3 +62,75 @@ def assert_grads_close(errs, tol, what='', outlier_frac=0.05, outlier_tol=1e-2):
     assert not hard, f'{what}: beyond the outlier bound {outlier_tol}: {hard[:8]}'
     assert len(bad) <= outlier_frac * max(1, len(items)), \
         f'{what}: {len(bad)}/{len(items)} tensors beyond tolerance (systematic): {[(k, e) for _, k, e in bad[:8]]}'
+
+
+SESSION_KERNELS = set()      # every conv-family kernel instantiation launched inside a `traced()` block of this session
+
+
+class traced:
+    """with traced() as tr: ...  ->  tr.names = the conv-family kernel instantiations launched inside the block
+    (tdvc_debug_trace; names normalised like rocprofv3's, e.g. 'conv_lean_kernel<1,4,1,4,0,0>')."""
+
+    def __enter__(self):
+        pkg()._lib.lib().tdvc_debug_trace(1)
+        self.names = set()
+        return self
+
+    def __exit__(self, *exc):
+        L = pkg()._lib
+        torch.cuda.synchronize()
+        self.names = set(L.traced_kernels())
+        L.lib().tdvc_debug_trace(0)
+        if exc[0] is None:
+            SESSION_KERNELS.update(self.names)
+        return False
+
+
+def param_sample_idx(key, numel, n=64):
+    """The element sample oracle/make_golden.py stores for each parameter tensor in step_*_update.npz."""
+    import zlib
+    import numpy as np
+    return np.random.RandomState(zlib.crc32(('upd:' + key).encode()) & 0x7FFFFFFF).randint(0, numel, size=min(n, numel))
+
+
+def feat_sample_idx(p_, m_, numel, n=48):
+    """The element sample oracle/make_golden.py stores for feature map m_ of discriminator pass p_ (disc_*.json)."""
+    import numpy as np
+    return np.random.RandomState(1000 + 10 * p_ + m_).randint(0, numel, size=min(n, numel))
+
+
+def assert_update_matches_fixture(models, gold_npz, before, lr, what=''):
+    """Post-AdamW parameters against the reference's, through the UPDATE p_after - p_before on the sampled elements
+    (an lr = 1e-4 step moves sum|p| by ~1e-5 relative: a checksum of p cannot see whether the optimizer ran).
+
+    Early Adam steps are ~ -lr * sign(g) per element, so an element whose gradient is below its own fp32 noise may
+    legitimately land lr..2*lr away; those must stay rare, everything else must agree closely, and every tensor's
+    update norm must match the reference's (an optimizer that did not run, or ran with another lr / bias correction,
+    fails all three)."""
+    import numpy as np
+    tot = flipped = 0
+    num = den = 0.0
+    bad_norm = {}
+    for tag, model in models.items():
+        for k, p in model.named_parameters():
+            ref_s = gold_npz[f'{tag}/{k}'].astype(np.float64)
+            dn_ref = float(gold_npz[f'{tag}/{k}/dnorm'])
+            b = before[tag][k].double().reshape(-1)
+            full = p.detach().double().cpu().reshape(-1)
+            dn_got = float((full - b).norm())
+            if dn_ref == 0.0:
+                assert dn_got == 0.0, f'{what} {tag}/{k}: the reference never updates this tensor (Q7)'
+                continue
+            if abs(dn_got - dn_ref) > 0.05 * dn_ref:
+                bad_norm[f'{tag}/{k}'] = (dn_got, dn_ref)
+            idx = param_sample_idx(k, p.numel())
+            d_got = (full[idx] - b[idx]).numpy()
+            d_ref = ref_s - b[idx].numpy()
+            fl = np.abs(d_got - d_ref) > 0.5 * lr
+            tot += fl.size; flipped += int(fl.sum())
+            num += float(((d_got - d_ref)[~fl] ** 2).sum()); den += float((d_ref[~fl] ** 2).sum())
+    frac, rel = flipped / max(1, tot), (num / max(den, 1e-300)) ** 0.5
+    assert not bad_norm, f'{what}: update norm differs from the reference by > 5 %: {dict(list(bad_norm.items())[:6])}'
+    assert frac <= 0.01, f'{what}: {frac:.4f} of the sampled elements moved differently by more than lr/2'
+    assert rel <= 2e-2, f'{what}: rel-L2 of the sampled update (well-conditioned elements) = {rel:.3e}'
+    return frac, rel

@@ -29,6 +29,36 @@ def main():
     assert bool((a.G[:1000] == tot).all()) and bool((a.G[1000:] == rank + 1).all()) and sync.scale == 1.0 / world
     sync.broadcast_params(a)
     assert bool((a.P == torch.arange(1010, dtype=torch.float32) * 2).all())      # rank 0 holds arange * (1 + 1)
+    # segment pipeline (the product path's schedule): completed segments are reduced as the "backward pass" reports them,
+    # the learning pass reduces everything at its end; either way every rank ends with the world sum, dead tail untouched
+    A = pkg.arena
+
+    class SegArena:
+        def __init__(self, fill):
+            self.seg_bounds = [0, 300, 700, 1000]
+            self.nseg, self.n_live = 3, 1000
+            self.G = torch.full((1010,), float(fill))
+            self.track = A.SegmentTracker(3)
+
+    seg_sync = pkg.parallel.GradSync()
+    order = [2, 2, 1, 0, 1, 0, 0]
+    for it in range(3):
+        sa = SegArena(rank + 1 + it)
+        sa.track.expected = None if it == 0 else sa_expected
+        sa.track.begin()
+        fired_early = []
+        for s in order:
+            if sa.track.note(s):
+                fired_early.append(s)
+                seg_sync.reduce_segment(sa, s)
+        for s in sa.track.finish():
+            seg_sync.reduce_segment(sa, s)
+        seg_sync.wait(sa)
+        sa_expected = sa.track.expected
+        want = sum(r + 1 + it for r in range(world))
+        assert bool((sa.G[:1000] == want).all()) and bool((sa.G[1000:] == rank + 1 + it).all()), it
+        assert fired_early == ([] if it == 0 else [2, 1, 0]), (it, fired_early)      # late layers' segment first
+    assert seg_sync.calls == 9
     # sharding contract with the oracle's D-step: gradient of the global batch == mean of shard gradients
     from common import filled_sd
     from oracle import losses as OL, model as OM

@@ -74,13 +74,11 @@ def _torch_ref(x, w, b, add, c):
     return y
 
 
-@pytest.mark.parametrize('generic', [0, 1], ids=['mfma', 'scalar'])
-@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
-def test_conv_fwd_bwd(case, generic, dev):
+def conv_case_errors(case, dev, generic=0, B=3):
+    """Forward, input-grad, weight-grad and bias-grad of one conv case through the C ABI vs float64 CPU autograd."""
     ops, L, arena = _mods()
     (name, cin, cout, k, s, p, d, g, reflect, transposed, T, pre, post) = case
     torch.manual_seed(sum(map(ord, name)))
-    B = 3
     wshape = (cin, cout // g, k) if transposed else (cout, cin // g, k)
     x = torch.randn(B, cin, T, dtype=torch.float64)
     w = torch.randn(wshape, dtype=torch.float64) / (wshape[1] * k) ** 0.5
@@ -109,7 +107,14 @@ def test_conv_fwd_bwd(case, generic, dev):
         e_dx, e_dw, e_db = rel_l2(xd.grad, xr.grad), rel_l2(dw, wr.grad), rel_l2(db, br.grad)
     finally:
         L.lib().tdvc_set_force_generic(0)
-    assert e_y < TOL and e_dx < TOL and e_dw < TOL and e_db < TOL, dict(y=e_y, dx=e_dx, dw=e_dw, db=e_db)
+    return dict(y=e_y, dx=e_dx, dw=e_dw, db=e_db)
+
+
+@pytest.mark.parametrize('generic', [0, 1], ids=['mfma', 'scalar'])
+@pytest.mark.parametrize('case', CASES, ids=[c[0] for c in CASES])
+def test_conv_fwd_bwd(case, generic, dev):
+    errs = conv_case_errors(case, dev, generic)
+    assert max(errs.values()) < TOL, errs
 
 
 @pytest.mark.parametrize('cfg', [(16, 3, 1, 900, True, True), (32, 7, 3, 400, True, False), (64, 11, 5, 260, False, True),
@@ -117,10 +122,15 @@ def test_conv_fwd_bwd(case, generic, dev):
                          ids=['c16k3', 'c32k7d3', 'c64k11d5_enc', 'c128k3', 'c256k11d5_enc'])
 def test_film_block(cfg, dev):
     """Fused FiLM residual block (model/generator.py:96-111) incl. MRF running-mean epilogue."""
+    errs = film_block_errors(cfg, dev)
+    assert max(errs.values()) < TOL, errs
+
+
+def film_block_errors(cfg, dev, B=2):
     ops, L, arena = _mods()
     C, k, d, T, cond, with_acc = cfg
     torch.manual_seed(C + k)
-    B, pad, scale = 2, (k * d - d) // 2, 1.0 / 3.0
+    pad, scale = (k * d - d) // 2, 1.0 / 3.0
     x = torch.randn(B, C, T, dtype=torch.float64)
     gb = torch.randn(B, 2 * C, T, dtype=torch.float64) * 0.5 if cond else None
     acc = torch.randn(B, C, T, dtype=torch.float64) if with_acc else None
@@ -161,7 +171,7 @@ def test_film_block(cfg, dev):
         errs['dgb'] = rel_l2(gbd.grad, gbr.grad)
     if with_acc:
         errs['dacc'] = rel_l2(accd.grad, accr.grad)
-    assert max(errs.values()) < TOL, errs
+    return errs
 
 
 @pytest.mark.parametrize('cfg', [(16, 2048, 2), (64, 600, 3), (128, 260, 2), (32, 64, 2)], ids=['C16_T2048', 'C64_T600', 'C128_T260', 'C32_T64'])
@@ -169,6 +179,11 @@ def test_film_conditioning_fused(cfg, dev):
     """tdvc_film_cond_fwd / tdvc_film_cond0_bwd (FiLM conditioning path of model/generator.py:86-92,103 in the split
     formulation) against float64 autograd of the dense reference formulation
         gb = cond_var.2(LeakyReLU(cond_var.0(cat([emb.repeat(T), exc]))))."""
+    errs = film_cond_errors(cfg, dev)
+    assert max(errs.values()) < TOL, errs
+
+
+def film_cond_errors(cfg, dev):
     ops, L, arena = _mods()
     C, T, B = cfg
     n_const, n_var = 128, 8
@@ -208,4 +223,4 @@ def test_film_conditioning_fused(cfg, dev):
     torch.cuda.synchronize()
     errs = dict(gb=rel_l2(gb, gbr), dexc=rel_l2(excd.grad, excr.grad), demb=rel_l2(embd.grad, embr.grad),
                 dw0=rel_l2(dw0, w0r.grad), db0=rel_l2(db0, b0r.grad), dw2=rel_l2(dw2, w2r.grad), db2=rel_l2(db2, b2r.grad))
-    assert max(errs.values()) < TOL, errs
+    return errs

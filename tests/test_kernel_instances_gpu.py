@@ -1,0 +1,178 @@
+"""Parity of the kernel INSTANCES the train step runs at its real launch shapes.
+
+`launch_conv_lean` picks its tile from the grid size (blocks >= 512), so small test shapes only ever reach the
+16x64 tile; the benchmark's launch shape (2 x 16 samples per conv) selects the 16/32/48/64-row x 256-column
+instances instead. Two complementary sweeps, both against float64 CPU autograd at 2e-5 rel-L2 per tensor:
+
+  (a) forced tiles: every lean tile configuration (tdvc_debug_force_tile) x every (prologue, epilogue) pair the step
+      uses, at small shapes with ragged ends (T % NT != 0), reflect-pad mirror folds up to pad 25 and 136-row tiles;
+  (b) launch shapes: the op cases of the B = 16 step (every trunk conv sees 32 samples, D layer 5 sees 64) with the
+      automatic tile choice — these also put the weight-grad kernels (conv_wgrad_pipe / _tile / _lean) in their
+      multi-chunk steady state and cover the generic strided / grouped / transposed kernel at its grid-aware tiles.
+
+Each case records which kernel instantiations it launched (tdvc_debug_trace) and asserts the expected one is among them,
+so a silent fall-back to another kernel cannot pass. test_zz_profile_coverage_gpu.py then checks that every tdvc kernel
+instance named in profiles/*kernel_stats.csv was launched by a passing test of this session.
+"""
+import importlib
+
+import pytest
+import torch
+
+import test_conv_ops_gpu as OPS
+from common import traced
+
+pytestmark = pytest.mark.gpu
+TOL = 2e-5
+
+LEAN_CFG = {0: (1, 4, 1, 4), 1: (2, 4, 1, 4), 2: (4, 4, 1, 4), 3: (1, 1, 1, 4), 4: (1, 4, 4, 1), 5: (3, 4, 1, 4), 6: (1, 2, 2, 2)}
+LXF_ACT, LXF_FILM, LXF_MASK_LRELU = 0, 1, 2
+EPI_FWD, EPI_MASK, EPI_FILM, EPI_PLAIN = 0, 1, 2, 3
+
+
+def _L():
+    return importlib.import_module('td-vc-gan_amd')._lib
+
+
+def lean_name(cfg, xfk, epi):
+    m, n, wm, wn = LEAN_CFG[cfg]
+    return f'conv_lean_kernel<{m},{n},{wm},{wn},{xfk},{epi}>'
+
+
+def _run_forced(cfg, fn):
+    L = _L()
+    L.lib().tdvc_debug_force_tile(cfg)
+    try:
+        with traced() as tr:
+            errs = fn()
+    finally:
+        L.lib().tdvc_debug_force_tile(-1)
+    return errs, tr.names
+
+
+# ------------------------------------------------------------------------------------------------ (a) forced tiles
+# FiLM block = dilated reflect conv (ACT/FWD) -> FiLM 1x1 posconv (FILM/FWD); backward: posconv input-grad (ACT/FILM),
+# dilated input-grad with the reflect mirror fold and the residual add (ACT/MASK).  (C, k, d, T, cond, with_acc)
+FILM_SHAPES = [(16, 3, 1, 520, True, True), (16, 11, 5, 332, True, False), (32, 7, 3, 520, True, True), (64, 11, 5, 332, True, True),
+               (64, 3, 1, 268, False, False), (128, 7, 5, 140, True, True)]
+
+
+@pytest.mark.parametrize('shape', FILM_SHAPES, ids=[f'C{c}k{k}d{d}T{t}' + ('' if cond else '_nocond') for c, k, d, t, cond, _ in FILM_SHAPES])
+@pytest.mark.parametrize('cfg', sorted(LEAN_CFG), ids=[f'tile{c}_' + 'x'.join(map(str, LEAN_CFG[c])) for c in sorted(LEAN_CFG)])
+def test_forced_tile_film_block(cfg, shape, dev):
+    errs, names = _run_forced(cfg, lambda: OPS.film_block_errors(shape, dev, B=2))
+    assert max(errs.values()) < TOL, errs
+    want = [lean_name(cfg, LXF_ACT, EPI_FWD), lean_name(cfg, LXF_ACT, EPI_MASK)]
+    want += [lean_name(cfg, LXF_FILM, EPI_FWD), lean_name(cfg, LXF_ACT, EPI_FILM)] if shape[4] else []
+    missing = [w for w in want if w not in names]
+    assert not missing, (missing, sorted(n for n in names if 'lean_kernel' in n))
+
+
+# Plain conv cases (tests/test_conv_ops_gpu.py layout): (name, cin, cout, k, stride, pad, dil, groups, reflect, transposed, T, pre, post)
+FORCED_CONV = [
+    # D-style layer: no prologue, in-place LeakyReLU after -> input-grad = MASK_LRELU prologue, PLAIN epilogue
+    ('d5_like_128_k5_lrelu', 128, 128, 5, 1, 2, 1, 1, False, False, 252, 0, 1, (LXF_MASK_LRELU, EPI_PLAIN)),
+    ('d5_like_256_k5_T63', 256, 256, 5, 1, 2, 1, 1, False, False, 63, 0, 1, (LXF_MASK_LRELU, EPI_PLAIN)),
+    # cond_var.0 dense (no activation either side) -> ACT/PLAIN input-grad; 136 rows = the 48-row tile's reason to exist
+    ('cond0_136_136', 136, 136, 3, 1, 1, 1, 1, False, False, 268, 0, 0, (LXF_ACT, EPI_PLAIN)),
+    # cond_var.2: LeakyReLU before, 136-row input-grad with the LeakyReLU mask epilogue
+    ('cond2_136_64', 136, 64, 3, 1, 1, 1, 1, False, False, 332, 1, 0, (LXF_ACT, EPI_MASK)),
+    ('cond2_136_256', 136, 256, 3, 1, 1, 1, 1, False, False, 140, 1, 0, (LXF_ACT, EPI_MASK)),
+    # reflect conv with the widest halo at a short sequence: both mirror folds inside one tile
+    ('dil_c32_k11_d5_T52', 32, 32, 11, 1, 25, 5, 1, True, False, 52, 1, 0, (LXF_ACT, EPI_MASK)),
+]
+
+
+@pytest.mark.parametrize('case', FORCED_CONV, ids=[c[0] for c in FORCED_CONV])
+@pytest.mark.parametrize('cfg', sorted(LEAN_CFG), ids=[f'tile{c}_' + 'x'.join(map(str, LEAN_CFG[c])) for c in sorted(LEAN_CFG)])
+def test_forced_tile_conv(cfg, case, dev):
+    T = case[10]
+    if T <= 80 and LEAN_CFG[cfg][1] * LEAN_CFG[cfg][3] * 16 == 256:
+        pytest.skip('256-column tiles are never selected for T <= 80 (launch_conv_lean)')
+    errs, names = _run_forced(cfg, lambda: OPS.conv_case_errors(case[:13], dev, 0, B=3))
+    assert max(errs.values()) < TOL, errs
+    want = [lean_name(cfg, LXF_ACT, EPI_FWD), lean_name(cfg, *case[13])]
+    missing = [w for w in want if w not in names]
+    assert not missing, (missing, sorted(n for n in names if 'lean_kernel' in n))
+
+
+# ------------------------------------------------------------------------------------------------ (b) launch shapes
+# FiLM blocks of the decoder MRFs at the step's launch shape: 2 x 16 samples, all (k, d) of the 16-channel stage,
+# the corner (k, d) pairs of the wider stages.  (C, k, d, T, cond, with_acc), B
+LAUNCH_FILM = [((16, k, d, 16000, True, d == 5), 32) for k in (3, 7, 11) for d in (1, 3, 5)] + \
+              [((32, 3, 1, 8000, True, False), 32), ((32, 11, 5, 8000, True, True), 32), ((32, 7, 3, 8000, False, False), 32),
+               ((64, 3, 1, 4000, True, False), 32), ((64, 11, 5, 4000, True, True), 32), ((64, 7, 3, 4000, False, False), 32),
+               ((128, 3, 1, 500, True, False), 32), ((128, 11, 5, 500, True, True), 32), ((128, 7, 3, 500, False, False), 32),
+               ((256, 3, 1, 50, False, False), 32), ((256, 11, 5, 50, False, True), 32)]
+
+
+@pytest.mark.parametrize('shape,B', LAUNCH_FILM, ids=[f'C{s[0]}k{s[1]}d{s[2]}T{s[3]}B{b}' + ('' if s[4] else '_enc') for s, b in LAUNCH_FILM])
+def test_launch_shape_film_block(shape, B, dev):
+    with traced() as tr:
+        errs = OPS.film_block_errors(shape, dev, B=B)
+    assert max(errs.values()) < TOL, (errs, sorted(tr.names))
+    assert any('conv_lean_kernel' in n for n in tr.names), sorted(tr.names)
+
+
+# (name, cin, cout, k, stride, pad, dil, groups, reflect, transposed, T, pre, post), B
+LAUNCH_CONV = [
+    # FiLM conditioning convs, dense formulation (cond_var.0) and cond_var.2 at every decoder stage
+    (('cond0_136_136_T4000', 136, 136, 3, 1, 1, 1, 1, False, False, 4000, 0, 0), 16),
+    (('cond2_136_32_T16000', 136, 32, 3, 1, 1, 1, 1, False, False, 16000, 1, 0), 32),
+    (('cond2_136_64_T8000', 136, 64, 3, 1, 1, 1, 1, False, False, 8000, 1, 0), 32),
+    (('cond2_136_128_T4000', 136, 128, 3, 1, 1, 1, 1, False, False, 4000, 1, 0), 32),
+    (('cond2_136_256_T500', 136, 256, 3, 1, 1, 1, 1, False, False, 500, 1, 0), 32),
+    # discriminator: layer 0, grouped strided layers 1-4, dense layer 5, output conv (real + fake = 2 x 16, with the
+    # sub-scale pass of discs 1 / 2 batched on top = 64)
+    (('d0_1_16_k15', 1, 16, 15, 1, 7, 1, 1, True, False, 16000, 0, 1), 32),
+    (('d1_grp_16_64', 16, 64, 41, 4, 20, 1, 4, False, False, 16000, 0, 1), 32),
+    (('d2_grp_64_256', 64, 256, 41, 4, 20, 1, 16, False, False, 4000, 0, 1), 32),
+    (('d3_grp_256_1024', 256, 1024, 41, 4, 20, 1, 64, False, False, 1000, 0, 1), 32),
+    (('d4_grp_1024_1024', 1024, 1024, 41, 4, 20, 1, 256, False, False, 250, 0, 1), 32),
+    (('d5_1024_1024_k5_T63', 1024, 1024, 5, 1, 2, 1, 1, False, False, 63, 0, 1), 64),
+    (('d5_1024_1024_k5_T32', 1024, 1024, 5, 1, 2, 1, 1, False, False, 32, 0, 1), 64),
+    (('dout_1024_16_k3_T63', 1024, 16, 3, 1, 1, 1, 1, False, False, 63, 0, 0), 64),
+    # encoder / decoder resampling convs, bottleneck convs, heads
+    (('enc0_1_16_k7', 1, 16, 7, 1, 3, 1, 1, True, False, 16000, 0, 0), 32),
+    (('down_16_32_s2', 16, 32, 4, 2, 1, 1, 1, False, False, 16000, 1, 0), 32),
+    (('down_32_64_s2', 32, 64, 4, 2, 1, 1, 1, False, False, 8000, 1, 0), 32),
+    (('down_64_128_s8', 64, 128, 16, 8, 4, 1, 1, False, False, 4000, 1, 0), 32),
+    (('down_128_256_s10', 128, 256, 20, 10, 5, 1, 1, False, False, 500, 1, 0), 32),
+    (('bott_256_256_k7_T50', 256, 256, 7, 1, 3, 1, 1, False, False, 50, 1, 0), 32),
+    (('bott_256_128_k7_T50', 256, 128, 7, 1, 3, 1, 1, False, False, 50, 1, 0), 32),
+    (('up_256_128_s10', 256, 128, 20, 10, 5, 1, 1, False, True, 50, 1, 0), 32),
+    (('up_128_64_s8', 128, 64, 16, 8, 4, 1, 1, False, True, 500, 1, 0), 32),
+    (('up_64_32_s2', 64, 32, 4, 2, 1, 1, 1, False, True, 4000, 1, 0), 32),
+    (('up_32_16_s2', 32, 16, 4, 2, 1, 1, 1, False, True, 8000, 1, 0), 32),
+    (('head_16_1_tanh', 16, 1, 7, 1, 3, 1, 1, True, False, 16000, 1, 2), 32),
+    (('head_64_1_tanh', 64, 1, 7, 1, 3, 1, 1, True, False, 4000, 1, 2), 32),
+    # excitation pyramid
+    (('exc_in_1_8_k7', 1, 8, 7, 1, 3, 1, 1, True, False, 16000, 0, 0), 32),
+    (('exc_8_8_k5', 8, 8, 5, 1, 2, 1, 1, False, False, 8000, 1, 0), 32),
+    (('exc_down_8_8_s2', 8, 8, 4, 2, 1, 1, 1, False, False, 16000, 0, 0), 32),
+    (('fir_dw8_k33_s2', 8, 8, 33, 2, 16, 1, 8, False, False, 16000, 0, 0), 32),
+    (('fir_1_k129_s2', 1, 1, 129, 2, 64, 1, 1, False, False, 16000, 0, 0), 32),
+    # STFT of the log-mel loss: Conv1d(1 -> 2*1028, K = 2048, stride 512) on the reflect-padded second of audio
+    (('stft_1_2056_k2048_s512', 1, 2056, 2048, 512, 0, 1, 1, False, False, 18048, 0, 0), 16),
+    (('mel_1028_80_k1', 1028, 80, 1, 1, 0, 1, 1, False, False, 32, 0, 0), 16),
+]
+
+
+@pytest.mark.parametrize('case,B', LAUNCH_CONV, ids=[f'{c[0]}_B{b}' for c, b in LAUNCH_CONV])
+def test_launch_shape_conv(case, B, dev):
+    with traced() as tr:
+        errs = OPS.conv_case_errors(case, dev, 0, B=B)
+    assert max(errs.values()) < TOL, (errs, sorted(tr.names))
+
+
+# fused conditioning forward (LXF_COND) + its one-pass backward at the four decoder stages: (C, T, B)
+LAUNCH_COND = [(16, 16000, 16), (32, 8000, 16), (64, 4000, 16), (128, 500, 32)]
+
+
+@pytest.mark.parametrize('cfg', LAUNCH_COND, ids=[f'C{c}_T{t}_B{b}' for c, t, b in LAUNCH_COND])
+def test_launch_shape_fused_conditioning(cfg, dev):
+    with traced() as tr:
+        errs = OPS.film_cond_errors(cfg, dev)
+    assert max(errs.values()) < TOL, (errs, sorted(tr.names))
+    assert any(n.startswith('conv_lean_kernel') and n.endswith(',4,0>') for n in tr.names), sorted(tr.names)
+    assert 'film_cond0_bwd_kernel' in tr.names, sorted(tr.names)
