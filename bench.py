@@ -2,70 +2,229 @@
 both AdamW updates) on the HIP path, config/conv_enc-stage1.yaml, 16 x 1 s of 16 kHz audio per GPU.
 
     python bench.py --gpus 1 --steps 20 --warmup 5
+    python bench.py --gpus 8 ...          # spawns its own ranks (torch.distributed.run, one fresh process per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
         bench.py --gpus N --steps K --warmup W
 
-Prints ONE JSON line on rank 0 (contract in the task statement). `roofline` is measured live with HIP
-events on the launch stream for the kernel named in it; `cpu_baseline` times the CPU oracle (a port of
-the reference's algorithm, pinned against the reference: oracle/) on this host's cores on a bounded sample.
+Prints ONE JSON line on rank 0 (contract in the task statement). `roofline` is measured live with HIP events on the
+launch stream: every kernel class of the table below is launched at the step's own launch shape on ROTATING buffer sets
+(> 512 MB per rotation, so nothing is served from the 256 MB Infinity Cache), its instance name is read back from the
+library (tdvc_debug_trace), and the entries are ranked by their share of the measured step time — the dominant kernel
+first. `cpu_baseline` times the CPU oracle (a port of the reference's algorithm, pinned against the reference: oracle/)
+on this host's cores on a bounded sample.
 """
 import argparse
+import ctypes as C
 import importlib
 import json
 import os
+import subprocess
 import sys
 import time
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
-sys.path.insert(0, ROOT)
-sys.path.insert(0, os.path.join(ROOT, 'tests'))
-
-import torch  # noqa: E402
-import torch.distributed as dist  # noqa: E402
-
 SR = 16000
 HBM_PEAK_GBS = 8000.0       # MI355X_MICROARCH.md: 8.0 TB/s spec
 MFMA_F32_PEAK_TF = 157.3    # fp32-input MFMA = fp32 vector peak
-PMC_TRAFFIC_BYTES = None     # filled from profiles/r01_pmc_traffic.txt below ((2*FETCH_SIZE + WRITE_SIZE) KiB per launch)
 
 
-def time_conv_kernel(pkg, dev, B, cin, cout, k, dil, T, iters=50):
-    """Average device time of ONE forward launch of the stride-1 dilated Conv1d kernel (reflect pad,
-    fused LeakyReLU-on-load + bias), HIP events on the launch stream."""
-    ops, arena, L = pkg.ops, pkg.arena, pkg._lib
-    pad = (k - 1) * dil // 2
-    spec = ops.ConvSpec(cin, cout, k, 1, pad, dil, 1, True)
-    w = torch.randn(cout, cin, k, device=dev) / (cin * k) ** 0.5
-    b = torch.randn(cout, device=dev) * 0.1
-    spec.slot = arena.ConvSlot(w.data_ptr(), b.data_ptr(), 0, 0, False, None)
-    x = torch.randn(B, cin, T, device=dev)
-    y = torch.empty(B, cout, T, device=dev)
-    xf = ops._xf(L.XF_LRELU)
-    for _ in range(5):
-        ops.conv_fwd_raw(spec, x, xf, out=y)
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=20)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--batch', type=int, default=16, help='samples per GPU (1 s each)')
+    ap.add_argument('--config', default='conv_enc-stage1')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-table', action='store_true')
+    ap.add_argument('--no-graph', action='store_true', help='run eagerly instead of replaying a captured hipGraph')
+    ap.add_argument('--force-dp', action='store_true', help='exercise the data-parallel code path (RCCL group, eager launches, '
+                                                            'segment-pipelined gradient all-reduce) even with one rank')
+    return ap.parse_args()
+
+
+def spawn_ranks_if_needed(args):
+    """`python bench.py --gpus N` without a launcher: start the N ranks as FRESH child processes through
+    torch.distributed.run and exit with their code. Decided before this process imports torch or touches a GPU."""
+    if args.gpus <= 1 or 'WORLD_SIZE' in os.environ or 'RANK' in os.environ:
+        return
+    port = 29400 + os.getpid() % 2000
+    env = dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY='0')
+    env.setdefault('OMP_NUM_THREADS', '4')
+    cmd = [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', '--nproc-per-node', str(args.gpus), '--master-addr', '127.0.0.1',
+           '--master-port', str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    raise SystemExit(subprocess.run(cmd, env=env).returncode)
+
+
+# ----------------------------------------------------------------------------------------------- kernel table
+class Bufs:
+    """Rotating operand sets for one micro-benchmark: `n` independent copies of every tensor, sized so that one
+    rotation moves > 512 MB — a buffer is long gone from the 256 MB Infinity Cache when its turn comes again."""
+
+    def __init__(self, torch, dev, shapes, min_bytes=600e6, max_sets=16):
+        per = sum(4 * int(torch.Size(s).numel()) for s in shapes.values())
+        self.n = int(max(2, min(max_sets, -(-min_bytes // per))))
+        self.sets = [{k: torch.randn(s, device=dev) * 0.5 for k, s in shapes.items()} for _ in range(self.n)]
+        self.bytes_per_rotation = per * self.n
+
+
+def time_launches(torch, calls, iters):
+    """Average device time of one launch over `iters` launches rotating through `calls`, HIP events on the launch stream."""
+    n = len(calls)
+    for i in range(n + 2):
+        calls[i % n]()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     torch.cuda.synchronize()
     e0.record()
-    for _ in range(iters):
-        ops.conv_fwd_raw(spec, x, xf, out=y)
+    for i in range(iters):
+        calls[i % n]()
     e1.record()
     torch.cuda.synchronize()
-    ms = e0.elapsed_time(e1) / iters
-    alg_bytes = 4.0 * B * (cin * T + cout * T) + 4.0 * (cout * cin * k + cout)
-    flops = 2.0 * B * T * cout * cin * k
-    return ms, alg_bytes, flops
+    return e0.elapsed_time(e1) / iters
 
 
-def pmc_traffic_bytes():
-    """HBM bytes per launch of the roofline kernel from the committed rocprofv3 PMC passes (2*FETCH_SIZE + WRITE_SIZE,
-    gfx950 correction per MI355X_MICROARCH.md); None when the profile file is absent."""
-    try:
-        for line in open(os.path.join(ROOT, 'profiles', 'r01_pmc_traffic.txt')):
-            if line.startswith('ROOFLINE_KERNEL_HBM_BYTES_PER_LAUNCH'):
-                return float(line.split('=')[1])
-    except OSError:
-        pass
-    return None
+def kernel_table(pkg, dev, B, step_ms, iters=40):
+    """Per-kernel roofline table at the step's launch shapes (B samples per GPU -> every trunk conv sees BL = 2B:
+    decoder [target; identity] conditionings, encoder [real; corrupted], discriminator [real; fake] / [fake; identity];
+    discs 1 and 2 see another x2 from the batched sub-scale pass). `n` = launches of that (op, shape) per iteration of
+    config/conv_enc-stage1.yaml: 9 FiLM blocks per decoder stage, one generator pass and three discriminator calls."""
+    import torch
+    ops, arena, L = pkg.ops, pkg.arena, pkg._lib
+    lib = L.lib()
+    BL = 2 * B
+    rows = []
+
+    def traced(call):
+        lib.tdvc_debug_trace(1)
+        call()
+        torch.cuda.synchronize()
+        names = sorted(L.traced_kernels())
+        lib.tdvc_debug_trace(0)
+        return ' + '.join(names)
+
+    def add(label, n, bound, alg_bytes, flops, calls, rot_bytes):
+        name = traced(calls[0])
+        ms = time_launches(torch, calls, iters)
+        ach_b, ach_f = alg_bytes / (ms * 1e-3) / 1e9, flops / (ms * 1e-3) / 1e12
+        e = dict(kernel=name, op=label, launches_per_step=n, ms_per_launch=ms, share_of_step=n * ms / step_ms, bound=bound,
+                 achieved=ach_b if bound == 'hbm' else ach_f, peak=HBM_PEAK_GBS if bound == 'hbm' else MFMA_F32_PEAK_TF,
+                 unit='GB/s' if bound == 'hbm' else 'TFLOP/s', algorithmic_bytes=alg_bytes, algorithmic_flops=flops,
+                 rotation_bytes=rot_bytes)
+        e['frac'] = e['achieved'] / e['peak']
+        rows.append(e)
+
+    def conv_case(label, n, bound, cin, cout, k, dil, T, reflect, pre, which, Bc, post=0, film=False):
+        pad = (k - 1) * dil // 2
+        spec = ops.ConvSpec(cin, cout, k, 1, pad, dil, 1, reflect)
+        w = torch.randn(cout, cin, k, device=dev) / (cin * k) ** 0.5
+        b = torch.randn(cout, device=dev) * 0.1
+        dw, db = torch.zeros_like(w), torch.zeros_like(b)
+        wt = w.permute(1, 0, 2).contiguous()
+        spec.slot = arena.ConvSlot(w.data_ptr(), b.data_ptr(), dw.data_ptr(), db.data_ptr(), True, None, wt.data_ptr())
+        keep.extend([w, b, dw, db, wt])
+        # operands of the launch exactly as the step passes them (distinct tensors for input / mask source / output)
+        if which == 'fwd':
+            shapes = dict(x=(Bc, cin, T), y=(Bc, cout, T))
+            if film:
+                shapes.update(gb=(Bc, 2 * cin, T), res=(Bc, cout, T))
+            words = cin + cout + ((2 * cin + cout) if film else 0)
+        elif which == 'dgrad':
+            shapes = dict(dy=(Bc, cout, T), dx=(Bc, cin, T))
+            if pre:
+                shapes['x_in'] = (Bc, cin, T)
+            if post:
+                shapes['act'] = (Bc, cout, T)
+            words = cout + cin + (cin if pre else 0) + (cout if post else 0)
+        else:
+            shapes = dict(x=(Bc, cin, T), dy=(Bc, cout, T))
+            if post:
+                shapes['act'] = (Bc, cout, T)
+            words = cin + cout + (cout if post else 0)
+        bufs = Bufs(torch, dev, shapes)
+        keep.append(bufs)
+        calls = []
+        for s in bufs.sets:
+            dyxf = (lambda s=s: ops._xf(L.XF_MASK_LRELU, aux=s['act'])) if post else (lambda s=s: ops._xf())
+            if which == 'fwd':
+                xf = ops._xf(L.XF_FILM_LRELU, aux=s['gb']) if film else ops._xf(L.XF_LRELU if pre else L.XF_NONE)
+                calls.append(lambda s=s, xf=xf: ops.conv_fwd_raw(spec, s['x'], xf, post=post, res=s.get('res'), out=s['y']))
+            elif which == 'dgrad':
+                calls.append(lambda s=s, f=dyxf: ops.conv_dgrad_raw(spec, s['dy'], f(), T, L.DG_MASK_LRELU if pre else L.DG_PLAIN,
+                                                                    x_in=s.get('x_in'), out=s['dx']))
+            else:
+                xf = ops._xf(L.XF_LRELU if pre else L.XF_NONE)
+                calls.append(lambda s=s, xf=xf, f=dyxf: ops.conv_wgrad_raw(spec, s['x'], xf, s['dy'], f()))
+        alg = 4.0 * Bc * T * words + 4.0 * (w.numel() + cout)
+        add(label, n, bound, alg, 2.0 * Bc * T * cin * cout * k, calls, bufs.bytes_per_rotation)
+
+    def cond_fwd_case(label, n, C2, T, Bc):
+        nc, nv = 136, 8
+        w0 = torch.randn(nc, nc, 3, device=dev) / (nc * 3) ** 0.5
+        w2 = torch.randn(C2, nc, 3, device=dev) / (nc * 3) ** 0.5
+        b2 = torch.randn(C2, device=dev) * 0.1
+        keep.extend([w0, w2, b2])
+        bufs = Bufs(torch, dev, dict(exc=(Bc, nv, T), k3=(Bc, nc, 3), cv0=(Bc, nc, T), gb=(Bc, C2, T)))
+        keep.append(bufs)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        calls = []
+        for s in bufs.sets:
+            a = L.FilmCondArgs(Bc, T, nc, nv, C2, s['exc'].data_ptr(), s['exc'].stride(0), w0.data_ptr(), s['k3'].data_ptr(), w2.data_ptr(),
+                               b2.data_ptr(), s['cv0'].data_ptr(), s['cv0'].stride(0), s['gb'].data_ptr(), s['gb'].stride(0), 0.2)
+            keep.append(a)
+            calls.append(lambda a=a: L.check(lib.tdvc_film_cond_fwd(C.byref(a), st)))
+        alg = 4.0 * Bc * T * (nv + nc + C2) + 4.0 * (w2.numel() + nc * nv * 3)
+        add(label, n, 'mfma', alg, 2.0 * Bc * T * (C2 * nc * 3 + nc * nv * 3), calls, bufs.bytes_per_rotation)
+
+    def cond0_bwd_case(label, n, T, Bc):
+        nc, nv = 136, 8
+        w0 = torch.randn(nc, nc, 3, device=dev) / (nc * 3) ** 0.5
+        dw0 = torch.zeros_like(w0)
+        keep.extend([w0, dw0])
+        bufs = Bufs(torch, dev, dict(dcv=(Bc, nc, T), exc=(Bc, nv, T), dexc=(Bc, nv, T), dk3=(Bc, nc, 3)))
+        keep.append(bufs)
+        nbytes = lib.tdvc_film_cond0_bwd_workspace(Bc, T, nc, nv)
+        ws = ops.workspace(dev, nbytes)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        calls = []
+        for s in bufs.sets:
+            a = L.FilmCond0BwdArgs(Bc, T, nc, nv, s['dcv'].data_ptr(), s['dcv'].stride(0), s['exc'].data_ptr(), s['exc'].stride(0), w0.data_ptr(),
+                                   s['dexc'].data_ptr(), s['dexc'].stride(0), s['dk3'].data_ptr(), dw0.data_ptr(), ws.data_ptr(),
+                                   ws.numel() * ws.element_size())
+            keep.append(a)
+            calls.append(lambda a=a: L.check(lib.tdvc_film_cond0_bwd(C.byref(a), st)))
+        add(label, n, 'hbm', 4.0 * Bc * T * (nc + 2 * nv), 2.0 * Bc * T * nc * nv * 3 * 2, calls, bufs.bytes_per_rotation)
+
+    keep = []
+    stages = [(32, 16000), (64, 8000), (128, 4000), (256, 500)]          # (2C, T) of the four decoder stages
+    for C2, T in stages:
+        tag = f'136->{C2} k3 T={T} B={BL}'
+        conv_case(f'FiLM cond_var.2 input-grad {tag}', 9, 'mfma', 136, C2, 3, 1, T, False, 1, 'dgrad', BL)
+        cond_fwd_case(f'FiLM conditioning fwd (cond_var.0 fused into cond_var.2) {tag}', 9, C2, T, BL)
+        conv_case(f'FiLM cond_var.2 weight-grad {tag}', 9, 'mfma', 136, C2, 3, 1, T, False, 1, 'wgrad', BL)
+        cond0_bwd_case(f'FiLM cond_var.0 backward (dexc + dW window + dk3) 136ch T={T} B={BL}', 9, T, BL)
+        keep.clear()
+    # discriminator layer 5 (1024 -> 1024, k5, T' = 63): disc 0 sees 2B, discs 1/2 see 4B (sub-scale pass batched on top)
+    conv_case(f'D layer5 1024->1024 k5 T=63 B={2 * BL} fwd', 4, 'mfma', 1024, 1024, 5, 1, 63, False, 0, 'fwd', 2 * BL, post=1)
+    conv_case(f'D layer5 1024->1024 k5 T=63 B={2 * BL} input-grad', 4, 'mfma', 1024, 1024, 5, 1, 63, False, 0, 'dgrad', 2 * BL, post=1)
+    conv_case(f'D layer5 1024->1024 k5 T=63 B={2 * BL} weight-grad', 2, 'mfma', 1024, 1024, 5, 1, 63, False, 0, 'wgrad', 2 * BL, post=1)
+    keep.clear()
+    # dilated trunk convs (decoder stage 4: C=16, T=16000; one launch per (k, d) and direction) and the FiLM 1x1 posconv
+    ns = {}
+    for k, d in ((3, 1), (7, 3), (11, 5)):
+        tag = f'dilated Conv1d 16->16 k{k} d{d} T=16000 B={BL}'
+        conv_case(f'{tag} fwd (reflect pad, LeakyReLU-on-load, bias)', 1, 'hbm', 16, 16, k, d, 16000, True, 1, 'fwd', BL)
+        ns[(k, d)] = rows[-1]
+        conv_case(f'{tag} input-grad (mirror fold + LeakyReLU mask)', 1, 'hbm', 16, 16, k, d, 16000, True, 1, 'dgrad', BL)
+        conv_case(f'{tag} weight-grad', 1, 'hbm', 16, 16, k, d, 16000, True, 1, 'wgrad', BL)
+        keep.clear()
+    conv_case(f'FiLM 1x1 posconv 16->16 T=16000 B={BL} fwd (h*(1+gamma)+beta on load, + residual)', 9, 'hbm', 16, 16, 1, 1, 16000, False, 1, 'fwd', BL,
+              film=True)
+    conv_case(f'dilated Conv1d 64->64 k7 d3 T=4000 B={BL} fwd', 2, 'mfma', 64, 64, 7, 3, 4000, True, 1, 'fwd', BL)
+    keep.clear()
+    torch.cuda.empty_cache()
+    north = ns[(3, 1)]
+    rows.sort(key=lambda e: -e['share_of_step'])
+    return rows, north
 
 
 def usable_cores():
@@ -83,8 +242,20 @@ def usable_cores():
     return max(1, min(n, 32))
 
 
-def cpu_baseline(pkg, cfg_train, iters=2):
+def cpu_model():
+    try:
+        for line in open('/proc/cpuinfo'):
+            if line.startswith('model name'):
+                return line.split(':', 1)[1].strip()
+    except OSError:
+        pass
+    return 'unknown'
+
+
+def cpu_baseline(pkg, cfg_train, iters=3):
     """CPU oracle timed on this host: B=2 x 1 s, 1 warm-up + `iters` timed iterations (~10-30 s)."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
     from common import filled_sd
     from oracle import step as OS
     cores = usable_cores()
@@ -99,22 +270,29 @@ def cpu_baseline(pkg, cfg_train, iters=2):
     for _ in range(iters):
         t0 = time.perf_counter(); st.run(bt, ix, iy); ts.append(time.perf_counter() - t0)
     t = sorted(ts)[len(ts) // 2]
-    return dict(value=B * T / SR / t, unit='audio-seconds/sec', cores=cores, kind='port',
-                sample=f'conv_enc-stage1 full D+G iteration, B={B} x 1 s, median of {iters} after 1 warm-up; '
-                       f'CPU oracle (torch {torch.__version__} CPU, {torch.get_num_threads()} threads)')
+    return dict(value=B * T / SR / t, unit='audio-seconds/sec', cores=cores, kind='port', cpu=cpu_model(),
+                sample=f'full D+G iteration of the same config, B={B} x 1 s, median of {iters} after 1 warm-up; '
+                       f'CPU oracle (torch {torch.__version__} CPU, {torch.get_num_threads()} threads; recomputes the G-step '
+                       'generator forward like the reference does, anomaly detection off)')
+
+
+def pmc_traffic(name):
+    """HBM bytes per launch of kernel `name` from the committed rocprofv3 PMC passes of this round (separate
+    --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, FETCH_SIZE doubled per MI355X_MICROARCH.md): profiles/r02_pmc_traffic.json."""
+    try:
+        tab = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')))
+        return tab.get('kernels', {}).get(name)
+    except (OSError, ValueError):
+        return None
 
 
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument('--gpus', type=int, default=1)
-    ap.add_argument('--steps', type=int, default=20)
-    ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--batch', type=int, default=16, help='samples per GPU (1 s each)')
-    ap.add_argument('--config', default='conv_enc-stage1')
-    ap.add_argument('--no-cpu-baseline', action='store_true')
-    ap.add_argument('--no-graph', action='store_true', help='run eagerly instead of replaying a captured hipGraph')
-    ap.add_argument('--force-dp', action='store_true', help='exercise the data-parallel code path (RCCL group, segmented graphs) even with one rank')
-    args = ap.parse_args()
+    args = parse_args()
+    spawn_ranks_if_needed(args)
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, 'tests'))
+    import torch
+    import torch.distributed as dist
 
     rank = int(os.environ.get('RANK', 0)); world = int(os.environ.get('WORLD_SIZE', 1))
     local = int(os.environ.get('LOCAL_RANK', 0))
@@ -133,8 +311,11 @@ def main():
 
     pkg = importlib.import_module('td-vc-gan_amd')
     from common import build_models, to_dev
+    import warnings
     hp = pkg.hparams.HParam(os.path.join(ROOT, 'config', f'{args.config}.yaml'))
-    cfg = pkg.train_step.StepConfig.from_hparams(hp.train)
+    with warnings.catch_warnings():
+        warnings.simplefilter('ignore')      # lambda_f0: the CREPE-backed term is excluded by contract (named in config.workload)
+        cfg = pkg.train_step.StepConfig.from_hparams(hp.train)
     G, D = build_models(dev)
     sync = pkg.parallel.GradSync() if dp else None
     if sync is not None:
@@ -186,35 +367,34 @@ def main():
         raise SystemExit('non-finite loss in the timed region')
 
     if rank == 0:
+        step_ms = dt / args.steps * 1e3
         value = world * B * (T / SR) * args.steps / dt
-        # roofline of the dilated Conv1d kernel the north star names (16->16, k=3, T=16000: the HBM-bound end).
-        # traffic: HBM bytes per launch from the committed rocprofv3 PMC pass (profiles/, FETCH_SIZE doubled per
-        # MI355X_MICROARCH.md) — not re-measured live (needs the profiler).
-        # Launch shape = the step's: every trunk conv runs on 2*B samples (decoder: [target; identity] conditionings,
-        # encoder: [real; corrupted], discriminator: [real; fake]), one launch per layer.
-        BL = 2 * B
-        ms, alg_bytes, flops = time_conv_kernel(pkg, dev, BL, 16, 16, 3, 1, T)
-        roof = dict(kernel=f'conv_lean_kernel<1,4,1,4,ACT,FWD> dilated Conv1d 16->16 k3 d1 T=16000 B={BL} fwd (fused LeakyReLU+bias)',
-                    bound='hbm', achieved=alg_bytes / (ms * 1e-3) / 1e9, peak=HBM_PEAK_GBS, unit='GB/s',
-                    frac=alg_bytes / (ms * 1e-3) / 1e9 / HBM_PEAK_GBS, traffic=pmc_traffic_bytes(), ms_per_launch=ms,
-                    algorithmic_bytes=alg_bytes)
-        # the FLOP-dominant kernel class of the step: FiLM conditioning conv 136 -> 2C, k3 (here C=64, T=4000); the fused
-        # conditioning forward and the cond_var.2 input-grad run the same tile / MFMA loop
-        ms2, _, fl2 = time_conv_kernel(pkg, dev, BL, 136, 128, 3, 1, 4000)
-        roof['mfma_kernel'] = dict(kernel=f'conv_lean_kernel<4,4,1,4,ACT,FWD> FiLM cond_var.2 136->128 k3 T=4000 B={BL} fwd', bound='mfma',
-                                   achieved=fl2 / (ms2 * 1e-3) / 1e12, peak=MFMA_F32_PEAK_TF, unit='TFLOP/s',
-                                   frac=fl2 / (ms2 * 1e-3) / 1e12 / MFMA_F32_PEAK_TF, ms_per_launch=ms2)
         stage = 'stage-1' if 'stage1' in args.config else args.config
         out = dict(metric=f'audio-seconds/sec (G+D train step, {stage})', value=value, unit='audio-seconds/sec', n_gpus=world,
-                   steps=args.steps, warmup=args.warmup, ms_per_step=dt / args.steps * 1e3, higher_is_better=True,
+                   steps=args.steps, warmup=args.warmup, ms_per_step=step_ms, higher_is_better=True,
                    scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
                    config=dict(workload=f'config/{args.config}.yaml full D+G iteration, {B} x 1 s @16 kHz per GPU, NUM_SPK=16, '
                                         'F0 (CREPE) loss term excluded', global_batch=world * B, parallelism=f'dp{world}'),
-                   roofline=roof, final_G_loss=g_loss, launch=launch)
+                   final_G_loss=g_loss, launch=launch)
+        if not args.no_kernel_table and 'stage1' in args.config:
+            table, north = kernel_table(pkg, dev, B, step_ms)
+            dom = table[0]
+            roof = {k: dom[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'kernel', 'op', 'ms_per_launch', 'launches_per_step',
+                                        'share_of_step', 'algorithmic_bytes', 'algorithmic_flops')}
+            roof['traffic'] = pmc_traffic(dom['kernel'])
+            roof['how'] = ('dominant kernel of the step by launches x measured time; HIP events on the launch stream over launches that rotate '
+                           f'through {dom["rotation_bytes"] / 1e6:.0f} MB of operand sets (nothing served from the 256 MB Infinity Cache); '
+                           'traffic = rocprofv3 PMC passes committed under profiles/ (null when absent)')
+            # the kernel the north star names: stride-1 dilated Conv1d, 16 -> 16, k3 (HBM-bound end of the trunk)
+            roof['north_star_kernel'] = dict(north, traffic=pmc_traffic(north['kernel']))
+            roof['kernels'] = [{k: e[k] for k in ('kernel', 'op', 'launches_per_step', 'ms_per_launch', 'share_of_step', 'bound', 'achieved',
+                                                  'peak', 'unit', 'frac')} for e in table[:12]]
+            roof['table_share_of_step'] = sum(e['share_of_step'] for e in table)
+            out['roofline'] = roof
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(pkg, hp.train)
             out['speedup_vs_cpu'] = value / out['cpu_baseline']['value']
-        print(json.dumps(out))
+        print(json.dumps(out), flush=True)
     if dp:
         dist.destroy_process_group()
 

@@ -196,6 +196,13 @@ int tdvc_concat_cond_bwd(const float* dc, float* demb, float* dexc, int B, int C
 int tdvc_edge_sum3(const float* d, float* out, int B, int C, int T, void* stream);
 int tdvc_axpby(const float* a, const float* b, float* y, float alpha, float beta, int64_t n, void* stream);      /* y = alpha*a + beta*b (b may be NULL) */
 int tdvc_fill(float* y, float value, int64_t n, void* stream);
+/* WaveNet gate of the SSL encoder's WN stack (model/ssl_encoder.py:8-15, fused_add_tanh_sigmoid_multiply):
+ * acts[b][c][t] = tanh(xin[b][c][t] + g[b][c][t]) * sigmoid(xin[b][H+c][t] + g[b][H+c][t]); xin / g are [B][2H][T]
+ * (g optional: NULL when the stack has no global conditioning, as in SSLEncoder), acts [B][H][T]; batch strides in elements.
+ * bwd: dxin [B][2H][T] from dacts [B][H][T] (the gradient wrt g equals dxin). */
+int tdvc_gate_fwd(const float* xin, int64_t xin_bs, const float* g, int64_t g_bs, float* acts, int64_t acts_bs, int B, int H, int T, void* stream);
+int tdvc_gate_bwd(const float* xin, int64_t xin_bs, const float* g, int64_t g_bs, const float* dacts, int64_t dacts_bs, float* dxin,
+                  int64_t dxin_bs, int B, int H, int T, void* stream);
 
 /* InstanceNorm1d(affine=False, eps) + conditional scale/shift: y = (1+gamma)*IN(x)+beta
  * (model/conditional_instance_norm.py:4-19). gb is [B][2C][Tg] with Tg = 1 (Linear path) or T (Conv path). */

@@ -241,3 +241,39 @@ def latent_classifier(sd, x, n_layers=3, p='classifier'):
     x = lrelu(conv(sd, f'{p}.{idx}', x, pad=2))
     x = conv(sd, f'{p}.{idx + 2}', x, pad=1)
     return x.mean(dim=2)
+
+
+# --------------------------------------------------------------------------- SSL (WavLM-side) content encoder
+def wn_stack(sd, p, x, n_layers, hidden, kernel_size=5, dilation_rate=1):
+    """WaveNet-style gated stack, g=None, x_mask=1, dropout 0 (model/ssl_encoder.py:17-90): per layer
+    x_in = in_i(x); acts = tanh(x_in[:H]) * sigmoid(x_in[H:]); rs = res_skip_i(acts); x += rs[:H]; out += rs[H:]
+    (the last layer's res_skip has H channels, all of which go to `out`)."""
+    out = torch.zeros_like(x)
+    for i in range(n_layers):
+        d = dilation_rate ** i
+        x_in = conv(sd, f'{p}.in_layers.{i}', x, pad=(kernel_size * d - d) // 2, dil=d)
+        acts = torch.tanh(x_in[:, :hidden]) * torch.sigmoid(x_in[:, hidden:])
+        rs = conv(sd, f'{p}.res_skip_layers.{i}', acts)
+        if i < n_layers - 1:
+            x = x + rs[:, :hidden]
+            out = out + rs[:, hidden:]
+        else:
+            out = out + rs
+    return out
+
+
+def ssl_content_encoder(sd, c, n_layers=16, emb_dim=128, kernel_size=5, dilation_rate=1, p='encoder.encoder'):
+    """SSLEncoder.forward after the (frozen, external) WavLM feature extractor (model/ssl_encoder.py:93-148):
+    pre (1x1) -> WN -> proj (1x1, 2*emb_dim channels); returns m = the first emb_dim channels (the sampled z is unused)."""
+    x = conv(sd, p + '.pre', c)
+    x = wn_stack(sd, p + '.enc', x, n_layers, emb_dim, kernel_size, dilation_rate)
+    stats = conv(sd, p + '.proj', x)
+    return stats[:, :emb_dim]
+
+
+def generator_ssl(sd, c_feat, c_tgt, c_var, ratios=(10, 8, 2, 2), n_layers=16):
+    """Generator with encoder_model='wavlm' (model/generator.py:453-454, 490-508), fed the SSL features [B,1024,T/320]."""
+    emb = F.linear(c_tgt, sd['embedding.weight'], sd['embedding.bias'])
+    content = ssl_content_encoder(sd, c_feat, n_layers)
+    y, subs = decoder(sd, content, emb, c_var, ratios)
+    return y, subs, content

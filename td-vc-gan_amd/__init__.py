@@ -17,7 +17,7 @@ from . import synth  # noqa: F401  (numpy/torch only, no GPU)
 def __getattr__(name):
     # heavy submodules on demand, so that `synth` stays importable without torch.cuda / the .so
     import importlib
-    if name in ('modules', 'losses', 'ops', 'arena', 'train_step', 'parallel', 'hparams', 'util', 'infer', '_lib'):
+    if name in ('modules', 'losses', 'ops', 'arena', 'train_step', 'parallel', 'hparams', 'util', 'infer', 'ssl_encoder', '_lib'):
         return importlib.import_module(f'{__name__}.{name}')
     if name in ('Generator', 'CollaborativeMultibandDiscriminator', 'ConditionalInstanceNorm', 'LatentClassifier', 'Discriminator'):
         return getattr(importlib.import_module(f'{__name__}.modules'), name)

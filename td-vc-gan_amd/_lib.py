@@ -95,6 +95,8 @@ SIGNATURES = {
     'tdvc_edge_sum3': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'tdvc_axpby': (_i, [_vp, _vp, _vp, _f, _f, _i64, _vp]),
     'tdvc_fill': (_i, [_vp, _f, _i64, _vp]),
+    'tdvc_gate_fwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _vp]),
+    'tdvc_gate_bwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _vp]),
     'tdvc_cin_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),
     'tdvc_cin_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'tdvc_mse_const_fwd': (_i, [_vp, _i64, _f, _f, _vp, _vp]),

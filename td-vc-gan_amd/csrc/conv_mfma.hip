@@ -648,11 +648,13 @@ hipError_t launch_slab_reduce(const float* slab, int nslab, long stride, long n,
   if (nslab > 8) { gy = 1024 / gx; if (gy > (nslab + 7) / 8) gy = (nslab + 7) / 8; if (gy < 1) gy = 1; }
   const int per_y = (nslab + gy - 1) / gy;
   gy = (nslab + per_y - 1) / per_y;
+  TDVC_TRACE(slab_reduce_kernel);
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(gx, gy), dim3(256), 0, st, slab, nslab, stride, n, dw, rowlen, dst_row_stride, per_y, n_w, dbias);
   return hipGetLastError();
 }
 
 hipError_t launch_bias_grad(const Opnd& a, int N, int Ctot, int B, float* dbias, hipStream_t st) {
+  TDVC_TRACE(conv_bias_grad_kernel);
   hipLaunchKernelGGL(conv_bias_grad_kernel, dim3(Ctot, B), dim3(256), 0, st, a, N, Ctot, dbias);
   return hipGetLastError();
 }

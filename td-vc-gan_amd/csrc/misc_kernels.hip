@@ -227,6 +227,33 @@ __global__ __launch_bounds__(256) void axpby_kernel(const float* a, const float*
     y[i] = alpha * a[i] + (b ? beta * b[i] : 0.f);
 }
 
+// ------------------------------------------------------------------------------ WaveNet gate (SSL encoder WN stack)
+// acts[b][c][t] = tanh(a) * sigmoid(s) with a = xin[b][c][t] (+ g), s = xin[b][H + c][t] (+ g') -- the reference's
+// fused_add_tanh_sigmoid_multiply (model/ssl_encoder.py:8-15). One thread per (b, c, t); T fastest -> coalesced.
+__global__ __launch_bounds__(256) void gate_fwd_kernel(const float* xin, long xin_bs, const float* g, long g_bs, float* acts, long acts_bs,
+                                                       int H, int T, long n) {
+  const long HT = (long)H * T;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long b = i / HT, r = i - b * HT;
+    float a = xin[b * xin_bs + r], s = xin[b * xin_bs + HT + r];
+    if (g) { a += g[b * g_bs + r]; s += g[b * g_bs + HT + r]; }
+    acts[b * acts_bs + r] = tanhf(a) * (1.f / (1.f + expf(-s)));
+  }
+}
+// d_xin[c] = d_acts * sig * (1 - tanh^2), d_xin[H + c] = d_acts * tanh * sig * (1 - sig)
+__global__ __launch_bounds__(256) void gate_bwd_kernel(const float* xin, long xin_bs, const float* g, long g_bs, const float* dacts, long dacts_bs,
+                                                       float* dxin, long dxin_bs, int H, int T, long n) {
+  const long HT = (long)H * T;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+    const long b = i / HT, r = i - b * HT;
+    float a = xin[b * xin_bs + r], s = xin[b * xin_bs + HT + r];
+    if (g) { a += g[b * g_bs + r]; s += g[b * g_bs + HT + r]; }
+    const float th = tanhf(a), sg = 1.f / (1.f + expf(-s)), d = dacts[b * dacts_bs + r];
+    dxin[b * dxin_bs + r] = d * sg * (1.f - th * th);
+    dxin[b * dxin_bs + HT + r] = d * th * sg * (1.f - sg);
+  }
+}
+
 __global__ __launch_bounds__(256) void fill_kernel(float* y, float v, long n) {
   for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) y[i] = v;
 }
@@ -594,6 +621,22 @@ extern "C" int tdvc_edge_sum3(const float* d, float* out, int B, int C, int T, v
 extern "C" int tdvc_axpby(const float* a, const float* b, float* y, float alpha, float beta, int64_t n, void* stream) {
   if (n <= 0) return TDVC_OK;
   hipLaunchKernelGGL(axpby_kernel, dim3(tdvc_grid(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, a, b, y, alpha, beta, (long)n);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+extern "C" int tdvc_gate_fwd(const float* xin, int64_t xin_bs, const float* g, int64_t g_bs, float* acts, int64_t acts_bs, int B, int H, int T,
+                             void* stream) {
+  if (!xin || !acts || B <= 0 || H <= 0 || T <= 0) return tdvc_fail(TDVC_EINVAL, "gate_fwd: bad argument");
+  const long n = (long)B * H * T;
+  hipLaunchKernelGGL(gate_fwd_kernel, dim3(tdvc_grid(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, xin, (long)xin_bs, g, (long)g_bs, acts,
+                     (long)acts_bs, H, T, n);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+extern "C" int tdvc_gate_bwd(const float* xin, int64_t xin_bs, const float* g, int64_t g_bs, const float* dacts, int64_t dacts_bs, float* dxin,
+                             int64_t dxin_bs, int B, int H, int T, void* stream) {
+  if (!xin || !dacts || !dxin || B <= 0 || H <= 0 || T <= 0) return tdvc_fail(TDVC_EINVAL, "gate_bwd: bad argument");
+  const long n = (long)B * H * T;
+  hipLaunchKernelGGL(gate_bwd_kernel, dim3(tdvc_grid(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, xin, (long)xin_bs, g, (long)g_bs, dacts,
+                     (long)dacts_bs, dxin, (long)dxin_bs, H, T, n);
   TDVC_CHECK_LAUNCH(); return TDVC_OK;
 }
 extern "C" int tdvc_fill(float* y, float value, int64_t n, void* stream) {

@@ -114,6 +114,14 @@ class ArenaModule(nn.Module):
     def _init_arena_state(self):
         self._arena = None
         self._frozen_weights = False
+        # a checkpoint loaded AFTER the arena exists (e.g. while a TrainStep holds the weights frozen) must refresh the
+        # effective weights w = g*v/||v||, otherwise forward() would keep using the old ones
+        self.register_load_state_dict_post_hook(ArenaModule._after_load)
+
+    @staticmethod
+    def _after_load(module, incompatible_keys):
+        if module._arena is not None:
+            module._arena.materialize()
 
     @property
     def arena(self) -> ParamArena:
@@ -333,7 +341,10 @@ class Generator(ArenaModule):
 
     def __init__(self, decoder_ratios, decoder_channels, num_bottleneck_layers, num_classes, conditional_dim,
                  content_dim=None, num_res_blocks=3, num_enc_layers=0, encoder_model=None, norm_layer=None,
-                 weight_norm=None, bot_cond='target', enc_cond=None, dec_cond=None, output_content_emb=False):
+                 weight_norm=None, bot_cond='target', enc_cond=None, dec_cond=None, output_content_emb=False, cmodel=None):
+        """Reference signature (model/generator.py:410-415) + `cmodel`: the frozen SSL feature extractor for
+        encoder_model='wavlm' (the reference loads wavlm/WavLM-Large.pt itself, model/ssl_encoder.py:126-133; that
+        checkpoint does not ship, so the module is injected — see ssl_encoder.SSLEncoder)."""
         super().__init__()
         self._init_arena_state()
         nls = norm_layer if isinstance(norm_layer, tuple) else (norm_layer,) * 3
@@ -342,14 +353,19 @@ class Generator(ArenaModule):
             raise NotImplementedError('norm layers other than Identity are not reachable from the shipped configs')
         if any(w != 'weight_norm' for w in wns):
             raise NotImplementedError('only weight_norm="weight_norm" is implemented')
-        if encoder_model not in (None, 'conv'):
-            raise NotImplementedError('SSL (WavLM) encoder is out of scope of the HIP path (SURVEY §2.1)')
+        if encoder_model not in (None, 'conv', 'wavlm'):
+            raise NotImplementedError(f'unknown encoder model {encoder_model!r}')
         if num_bottleneck_layers != 0 or bot_cond != 'target' or enc_cond is not None or dec_cond is None:
             raise NotImplementedError('only the shipped conditioning layout is implemented '
                                       '(0 bottleneck layers, encoder unconditioned, decoder on target)')
         self.output_content_emb = output_content_emb
         self.decoder = Decoder(decoder_ratios, list(decoder_channels), conditional_dim, content_dim)
-        self.encoder = Encoder(decoder_ratios[::-1], list(decoder_channels)[::-1], content_dim)
+        if encoder_model == 'wavlm':      # model/generator.py:453-454
+            from .ssl_encoder import SSLEncoder
+            self.encoder = SSLEncoder(encoder_model, num_enc_layers, content_dim, cmodel=cmodel)
+            self.dead_prefixes = Generator.dead_prefixes + ('encoder.cmodel.',)     # frozen: never in the optimizer's live prefix
+        else:
+            self.encoder = Encoder(decoder_ratios[::-1], list(decoder_channels)[::-1], content_dim)
         import weakref
         self.encoder._top = weakref.ref(self)
         self.bottleneck = nn.ModuleList()

@@ -420,3 +420,81 @@ def axpby(a, b, alpha, beta):
     L.check(L.lib().tdvc_axpby(a.data_ptr(), b.data_ptr() if b is not None else None, y.data_ptr(), alpha, beta,
                                a.numel(), _stream(a)))
     return y
+
+
+# ------------------------------------------------------------------------------- SSL encoder: WaveNet gated stack
+def _gate_fwd(xin, H):
+    B, _, T = xin.shape
+    acts = torch.empty((B, H, T), dtype=torch.float32, device=xin.device)
+    L.check(L.lib().tdvc_gate_fwd(xin.data_ptr(), _bs(xin), None, 0, acts.data_ptr(), _bs(acts), B, H, T, _stream(xin)))
+    return acts
+
+
+def _gate_bwd(xin, dacts, H):
+    B, _, T = xin.shape
+    dxin = torch.empty_like(xin)
+    L.check(L.lib().tdvc_gate_bwd(xin.data_ptr(), _bs(xin), None, 0, dacts.data_ptr(), _bs(dacts), dxin.data_ptr(), _bs(dxin), B, H, T, _stream(xin)))
+    return dxin
+
+
+class WnStackFn(Function):
+    """The gated WaveNet stack of the SSL content encoder (model/ssl_encoder.py:52-82, WN.forward with g=None,
+    x_mask=1, dropout 0). Per layer i:
+        x_in = in_i(x);  acts = tanh(x_in[:H]) * sigmoid(x_in[H:]);  rs = res_skip_i(acts)
+        i < n-1:  x += rs[:H], out += rs[H:]          last layer: out += rs  (H channels)
+    The running pair lives in ONE state tensor S = [x ; out] ([B, 2H, T]), so res_skip's residual epilogue updates both
+    halves in a single launch; the in-layer reads the x half through its batch stride. Three launches per layer forward
+    (conv, gate, conv); backward = the convs' input/weight-grad kernels plus the gate's backward."""
+
+    @staticmethod
+    def forward(ctx, x, token, in_specs, rs_specs):
+        x = x.contiguous()
+        B, H, T = x.shape
+        n = len(in_specs)
+        S = torch.zeros((B, 2 * H, T), dtype=torch.float32, device=x.device)
+        S[:, :H].copy_(x)
+        states, xins, actss = [], [], []
+        for i in range(n):
+            states.append(S)
+            xin = conv_fwd_raw(in_specs[i], S[:, :H], _xf())
+            acts = _gate_fwd(xin, H)
+            xins.append(xin); actss.append(acts)
+            if i < n - 1:
+                S = conv_fwd_raw(rs_specs[i], acts, _xf(), res=S)
+            else:
+                out = conv_fwd_raw(rs_specs[i], acts, _xf(), res=S[:, H:])
+        ctx.in_specs, ctx.rs_specs, ctx.H = in_specs, rs_specs, H
+        ctx.save_for_backward(*states, *xins, *actss)
+        return out
+
+    @staticmethod
+    def backward(ctx, d_out):
+        n, H = len(ctx.in_specs), ctx.H
+        saved = ctx.saved_tensors
+        states, xins, actss = saved[:n], saved[n:2 * n], saved[2 * n:]
+        d_out = d_out.contiguous()
+        B, _, T = d_out.shape
+        # dS = gradient wrt the state [x ; out] entering layer i+1; its `out` half is d_out for every layer
+        bufs = [torch.empty((B, 2 * H, T), dtype=torch.float32, device=d_out.device) for _ in range(2)]
+        for b in bufs:
+            b[:, H:].copy_(d_out)
+        dS = None
+        for i in reversed(range(n)):
+            dy = d_out if i == n - 1 else dS
+            conv_wgrad_raw(ctx.rs_specs[i], actss[i], _xf(), dy, _xf())
+            d_acts = conv_dgrad_raw(ctx.rs_specs[i], dy, _xf(), T, L.DG_PLAIN)
+            d_xin = _gate_bwd(xins[i], d_acts, H)
+            x_i = states[i][:, :H]
+            conv_wgrad_raw(ctx.in_specs[i], x_i, _xf(), d_xin, _xf())
+            nxt = bufs[i & 1]
+            if i == n - 1:      # the last layer leaves x untouched: no residual-path gradient
+                conv_dgrad_raw(ctx.in_specs[i], d_xin, _xf(), T, L.DG_PLAIN, out=nxt[:, :H])
+            else:
+                conv_dgrad_raw(ctx.in_specs[i], d_xin, _xf(), T, L.DG_PLAIN, add=dS[:, :H], add_scale=1.0, out=nxt[:, :H])
+            dS = nxt
+        dx = dS[:, :H].contiguous() if ctx.needs_input_grad[0] else None
+        return dx, None, None, None
+
+
+def wn_stack(x, in_specs, rs_specs):
+    return WnStackFn.apply(x, _token(*in_specs, *rs_specs), list(in_specs), list(rs_specs))

@@ -33,3 +33,56 @@ def f0_to_excitation(f0, step_size, sampling_rate=16000, linear=True, noise=None
                                           B, nf, int(step_size), float(sampling_rate), int(bool(linear)),
                                           torch.cuda.current_stream(dev).cuda_stream))
     return exc
+
+
+def load_possible(model, state_dict):
+    """Permissive checkpoint load (reference: util/__init__.py:64-89, same name / arguments / return value): tensors whose
+    key and shape match are taken over, tensors whose key matches but whose shape differs are copied on their common
+    leading slices, everything else is reported. Returns the reference's message dict
+    {'matched', 'mismatched_size', 'unmatched_keys', 'missing_keys'}.
+
+    One deliberate difference: the reference only REBINDS matched entries in a throw-away dict and relies on the failed
+    strict `load_state_dict` that precedes it in train.py:58-68 (which copies every shape-compatible tensor before it
+    raises) to have loaded them; here matched tensors are copied in place as well, so the function is correct on its own.
+    Arena-backed models refresh their effective weights afterwards."""
+    own = model.state_dict()
+    messages = {'matched': [], 'mismatched_size': [], 'unmatched_keys': [], 'missing_keys': []}
+    with torch.no_grad():
+        for k, v in state_dict.items():
+            if k not in own:
+                messages['unmatched_keys'].append(k)
+                continue
+            dst = own[k]
+            if v.shape == dst.shape:
+                dst.copy_(v)
+                messages['matched'].append(k)
+            elif v.dim() == dst.dim():
+                sl = tuple(slice(0, min(a, b)) for a, b in zip(dst.shape, v.shape))
+                dst[sl] = v[sl].to(dst.dtype)
+                messages['mismatched_size'].append(k)
+            else:
+                raise RuntimeError(f'load_possible: {k} has {v.dim()} dims in the checkpoint and {dst.dim()} in the model')
+    for k in own:
+        if k not in state_dict:
+            messages['missing_keys'].append(k)
+    arena = getattr(model, '_arena', None)
+    if arena is not None:
+        arena.materialize()
+    return messages
+
+
+def load_model(model, path):
+    """train.py:58-68 — strict load, falling back to `load_possible`. The file is read with weights_only=True: nothing
+    from a checkpoint is ever executed."""
+    state_dict = torch.load(path, map_location='cpu', weights_only=True)
+    try:
+        model.load_state_dict(state_dict)
+        return None
+    except RuntimeError:
+        print(f'Warning: default loading for {path} failed. Trying permisive load')
+        messages = load_possible(model, state_dict)
+        for kind, keys in messages.items():
+            if kind != 'matched':
+                for k in keys:
+                    print(f'{kind}: {k}')
+        return messages

@@ -45,7 +45,10 @@ def test_state_dict_matches_reference_layout():
 def test_unsupported_configurations_raise():
     M = pkg().modules
     with pytest.raises(NotImplementedError):
-        M.Generator(**{**G_ARGS, 'encoder_model': 'wavlm'})
+        M.Generator(**{**G_ARGS, 'encoder_model': 'hubert'})       # only 'conv' and 'wavlm' exist (model/generator.py:453)
+    G = M.Generator(**{**G_ARGS, 'encoder_model': 'wavlm'})         # SSL content encoder: state_dict layout of model/ssl_encoder.py
+    ref_keys = set(json.load(open(os.path.join(GOLDEN, 'shapes_SSLENC.json'))))
+    assert {k[len('encoder.encoder.'):] for k in G.state_dict() if k.startswith('encoder.')} == ref_keys
     with pytest.raises(NotImplementedError):
         M.Generator(**{**G_ARGS, 'norm_layer': ('instance_norm',) * 3})
 

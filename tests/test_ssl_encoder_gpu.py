@@ -1,0 +1,93 @@
+"""GPU parity of the SSL content encoder (model/ssl_encoder.py:17-116 — pre 1x1, 16-layer gated WaveNet
+stack k=5, proj 1x1) and of `Generator(encoder_model='wavlm')`:
+  * tests/golden/ssl_encoder.* = the REFERENCE module's output m, input gradient and parameter gradients on the same
+    deterministic weights and seeded features (oracle/make_golden_ssl.py);
+  * the CPU oracle (every gradient element, rel-L2 per tensor);
+  * the full generator fed SSL features (conv decoder + SSL encoder) against the oracle, forward and backward.
+The WavLM feature extractor is an injected module and not part of this path (see ssl_encoder.py)."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+from common import G_ARGS, GOLDEN, assert_grads_close, filled_sd, pkg, rel_l2, to_dev, traced
+
+pytestmark = pytest.mark.gpu
+TOL = 1e-3
+
+
+def _ssl_generator(dev):
+    P = pkg()
+    G = P.modules.Generator(**{**G_ARGS, 'encoder_model': 'wavlm', 'decoder_channels': list(G_ARGS['decoder_channels'])})
+    shapes = json.load(open(os.path.join(GOLDEN, 'shapes_SSLENC.json')))
+    sd_enc = {'encoder.encoder.' + k: v for k, v in P.synth.fill_state_dict(shapes).items()}
+    sd = {k: v for k, v in filled_sd('G').items() if not k.startswith('encoder.')}
+    sd.update(sd_enc)
+    assert set(sd) == set(G.state_dict()), set(sd) ^ set(G.state_dict())
+    G.load_state_dict(sd)
+    G.ensure_arena(dev)
+    return G, sd
+
+
+def test_ssl_encoder_vs_reference_golden_and_oracle(dev):
+    from oracle import model as OM
+    G, sd = _ssl_generator(dev)
+    gold = np.load(os.path.join(GOLDEN, 'ssl_encoder.npz'))
+    gj = json.load(open(os.path.join(GOLDEN, 'ssl_encoder.json')))
+    rs = np.random.RandomState(77)
+    c = torch.from_numpy(rs.randn(2, 1024, 100).astype(np.float32))
+    cot = torch.from_numpy(rs.randn(2, 128, 100).astype(np.float32))
+    G.arena.zero_grad()
+    cd = c.to(dev).requires_grad_(True)
+    with traced():
+        m = G.encoder(cd)
+        (m * cot.to(dev)).mean().backward()
+        torch.cuda.synchronize()
+    assert rel_l2(m, torch.from_numpy(gold['m'])) < TOL and rel_l2(cd.grad, torch.from_numpy(gold['dc'])) < TOL
+    so = {k: v.clone().requires_grad_(True) for k, v in sd.items() if k.startswith('encoder.')}
+    co = c.clone().requires_grad_(True)
+    (OM.ssl_content_encoder(so, co) * cot).mean().backward()
+    params = dict(G.named_parameters())
+    errs, samp = {}, {}
+    for k, v in so.items():
+        errs[k] = rel_l2(params[k].grad, v.grad)
+        kk = k[len('encoder.encoder.'):]
+        n_ref = gj['norms'][kk]
+        idx, vals = gj['samples'][kk]
+        got = params[k].grad.reshape(-1)[torch.tensor(idx, device=dev)].double().cpu()
+        samp[k] = float((got - torch.tensor(vals)).norm()) / (n_ref / max(1.0, params[k].numel() ** 0.5) * 4 + 1e-30)
+        assert abs(float(params[k].grad.double().norm()) - n_ref) <= TOL * n_ref, k
+    assert max(errs.values()) < 1e-4, {k: e for k, e in errs.items() if e > 1e-4}
+    assert max(samp.values()) < 0.05, {k: e for k, e in samp.items() if e > 0.05}
+    assert rel_l2(cd.grad, co.grad) < 1e-4
+
+
+def test_generator_with_ssl_encoder_vs_oracle(dev):
+    from oracle import model as OM
+    P = pkg()
+    G, sd = _ssl_generator(dev)
+    B, T = 2, 8960
+    bt_cpu = P.synth.make_batch(B, T, seed=51)
+    bt = to_dev(bt_cpu, dev)
+    feat = torch.from_numpy(np.random.RandomState(52).randn(B, 1024, T // 320).astype(np.float32))
+    so = {k: v.clone().requires_grad_(True) for k, v in sd.items()}
+    oy, osubs, oemb = OM.generator_ssl(so, feat, bt_cpu['c_tgt'], bt_cpu['c_f0_conv'])
+    rs = np.random.RandomState(5)
+    cot = [torch.from_numpy(rs.randn(*t.shape).astype(np.float32)) for t in (oy, osubs[0], osubs[1], oemb)]
+    sum((t * c).mean() for t, c in zip((oy, osubs[0], osubs[1], oemb), cot)).backward()
+    G.output_content_emb = True
+    G.arena.zero_grad()
+    y, subs = G(feat.to(dev), bt['c_tgt'], c_var=bt['c_f0_conv'], out_subsample=True)
+    outs = (y, subs[0], subs[1], G.content_embedding)
+    sum((t * c.to(dev)).mean() for t, c in zip(outs, cot)).backward()
+    torch.cuda.synchronize()
+    errs = dict(y=rel_l2(y, oy), sub4=rel_l2(subs[0], osubs[0]), sub2=rel_l2(subs[1], osubs[1]), emb=rel_l2(G.content_embedding, oemb))
+    assert max(errs.values()) < TOL, errs
+    gerrs = {k: rel_l2(p.grad, so[k].grad) for k, p in G.named_parameters() if p.grad is not None and so[k].grad is not None}
+    assert len(gerrs) > 500
+    assert_grads_close(gerrs, TOL, 'generator (SSL encoder) gradients vs oracle')
+    # a waveform cannot be fed without the injected feature extractor
+    with pytest.raises(RuntimeError):
+        G(bt['signal_real'], bt['c_tgt'], c_var=bt['c_f0_conv'])
