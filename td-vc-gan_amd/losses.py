@@ -76,24 +76,126 @@ def cross_entropy_loss(logits, labels):
     return CrossEntropyFn.apply(logits, labels)
 
 
-def lsgan_loss(outs, target):
-    return MseConstFn.apply(float(target), *outs)
+def _rows(x, lo, hi):
+    """(byte offset, element count) of samples [lo, hi) of a batch-major contiguous tensor."""
+    per = x[0].numel()
+    return 4 * lo * per, (hi - lo) * per
+
+
+def _zero_outside(dx, lo, hi, lib):
+    """Zero the rows of dx outside [lo, hi) (the loss does not see them)."""
+    N = dx.shape[0]
+    st = _stream(dx)
+    if lo > 0:
+        off, n = _rows(dx, 0, lo)
+        L.check(lib.tdvc_fill(dx.data_ptr() + off, 0.0, n, st))
+    if hi < N:
+        off, n = _rows(dx, hi, N)
+        L.check(lib.tdvc_fill(dx.data_ptr() + off, 0.0, n, st))
+
+
+class MseConstRangeFn(Function):
+    """sum_i mean((x_i[lo:hi] - target)^2): the LSGAN term on a sample range of BATCHED discriminator outputs. The
+    gradient is produced directly at full batch size (zero outside the range), so no slice copy / zero-pad / add kernels
+    appear in the backward pass."""
+
+    @staticmethod
+    def forward(ctx, target, lo, hi, *xs):
+        xs = [x.contiguous() for x in xs]
+        out = _ScalarOut.new(xs[0])
+        lib = L.lib()
+        for x in xs:
+            off, n = _rows(x, lo, hi)
+            L.check(lib.tdvc_mse_const_fwd(x.data_ptr() + off, n, target, 1.0, out.data_ptr(), _stream(x)))
+        ctx.args = (target, lo, hi)
+        ctx.save_for_backward(*xs)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        target, lo, hi = ctx.args
+        g = g.contiguous()
+        lib = L.lib()
+        grads = []
+        for x in ctx.saved_tensors:
+            dx = torch.empty_like(x)
+            _zero_outside(dx, lo, hi, lib)
+            off, n = _rows(x, lo, hi)
+            L.check(lib.tdvc_mse_const_bwd(x.data_ptr() + off, n, target, 1.0, g.data_ptr(), dx.data_ptr() + off, _stream(x)))
+            grads.append(dx)
+        return (None, None, None, *grads)
+
+
+class LsganSplitFn(Function):
+    """D-step losses on outputs of ONE discriminator call over [real; fake] (train.py:271-281): returns
+    (sum_i mean((x_i[:B] - 1)^2), sum_i mean(x_i[B:]^2)) and writes both gradient halves into one tensor per output."""
+
+    @staticmethod
+    def forward(ctx, B, *xs):
+        xs = [x.contiguous() for x in xs]
+        l_real, l_fake = _ScalarOut.new(xs[0]), _ScalarOut.new(xs[0])
+        lib = L.lib()
+        for x in xs:
+            N = x.shape[0]
+            o0, n0 = _rows(x, 0, B)
+            o1, n1 = _rows(x, B, N)
+            L.check(lib.tdvc_mse_const_fwd(x.data_ptr() + o0, n0, 1.0, 1.0, l_real.data_ptr(), _stream(x)))
+            L.check(lib.tdvc_mse_const_fwd(x.data_ptr() + o1, n1, 0.0, 1.0, l_fake.data_ptr(), _stream(x)))
+        ctx.B = B
+        ctx.save_for_backward(*xs)
+        return l_real, l_fake
+
+    @staticmethod
+    def backward(ctx, g_real, g_fake):
+        lib = L.lib()
+        xs = ctx.saved_tensors
+        zero = None
+        if g_real is None or g_fake is None:
+            zero = torch.zeros(1, dtype=torch.float32, device=xs[0].device)
+        g_real = g_real.contiguous() if g_real is not None else zero
+        g_fake = g_fake.contiguous() if g_fake is not None else zero
+        grads = []
+        for x in xs:
+            dx = torch.empty_like(x)
+            o0, n0 = _rows(x, 0, ctx.B)
+            o1, n1 = _rows(x, ctx.B, x.shape[0])
+            L.check(lib.tdvc_mse_const_bwd(x.data_ptr() + o0, n0, 1.0, 1.0, g_real.data_ptr(), dx.data_ptr() + o0, _stream(x)))
+            L.check(lib.tdvc_mse_const_bwd(x.data_ptr() + o1, n1, 0.0, 1.0, g_fake.data_ptr(), dx.data_ptr() + o1, _stream(x)))
+            grads.append(dx)
+        return (None, *grads)
+
+
+def lsgan_loss(outs, target, rng=None):
+    """rng = (lo, hi): the outputs are batched over several signals and only samples [lo, hi) enter this term."""
+    if rng is None:
+        return MseConstFn.apply(float(target), *outs)
+    return MseConstRangeFn.apply(float(target), int(rng[0]), int(rng[1]), *outs)
+
+
+def lsgan_split(outs, B):
+    """(real term on samples [0, B), fake term on samples [B, N)) of one batched discriminator call."""
+    return LsganSplitFn.apply(int(B), *outs)
 
 
 class L1PairsFn(Function):
-    """sum over pairs of mean|a - b| (b carries no gradient)."""
+    """sum over pairs of mean|a[lo:hi] - b| (b carries no gradient). With a sample range the a's are BATCHED feature
+    maps (several signals through the discriminator in one call); their gradient comes out at full batch size, zero
+    outside the range — the slice / zero-pad / copy kernels autograd would otherwise run on 30 feature maps of up to
+    33 MB each were 4 % of the iteration."""
 
     @staticmethod
-    def forward(ctx, n, *ab):
+    def forward(ctx, n, lo, hi, *ab):
         a = [t.contiguous() for t in ab[:n]]
         b = [t.contiguous() for t in ab[n:]]
         out = _ScalarOut.new(a[0])
         lib = L.lib()
         for x, y in zip(a, b):
-            if x.shape != y.shape:
-                raise RuntimeError(f'l1 pair shape mismatch {tuple(x.shape)} vs {tuple(y.shape)}')
-            L.check(lib.tdvc_l1_fwd(x.data_ptr(), y.data_ptr(), x.numel(), 1.0, out.data_ptr(), _stream(x)))
-        ctx.n = n
+            h = x.shape[0] if hi is None else hi
+            if x[lo:h].shape != y.shape:
+                raise RuntimeError(f'l1 pair shape mismatch {tuple(x[lo:h].shape)} vs {tuple(y.shape)}')
+            off, cnt = _rows(x, lo, h)
+            L.check(lib.tdvc_l1_fwd(x.data_ptr() + off, y.data_ptr(), cnt, 1.0, out.data_ptr(), _stream(x)))
+        ctx.n, ctx.lo, ctx.hi = n, lo, hi
         ctx.save_for_backward(*a, *b)
         return out
 
@@ -105,18 +207,24 @@ class L1PairsFn(Function):
         lib = L.lib()
         grads = []
         for x, y in zip(a, b):
+            h = x.shape[0] if ctx.hi is None else ctx.hi
             dx = torch.empty_like(x)
-            L.check(lib.tdvc_l1_bwd(x.data_ptr(), y.data_ptr(), x.numel(), 1.0, g.data_ptr(), dx.data_ptr(), 0, _stream(x)))
+            _zero_outside(dx, ctx.lo, h, lib)
+            off, cnt = _rows(x, ctx.lo, h)
+            L.check(lib.tdvc_l1_bwd(x.data_ptr() + off, y.data_ptr(), cnt, 1.0, g.data_ptr(), dx.data_ptr() + off, 0, _stream(x)))
             grads.append(dx)
-        return (None, *grads, *([None] * n))
+        return (None, None, None, *grads, *([None] * n))
 
 
-def multiscale_feat_loss(feat_sig_list, feat_ref_list, norm_p=1):
+def multiscale_feat_loss(feat_sig_list, feat_ref_list, norm_p=1, rng=None):
+    """util/losses.py:55-68. rng = (lo, hi): `feat_sig_list` holds feature maps of a discriminator call batched over
+    several signals and only samples [lo, hi) are the signal of this term (product-side extension, see L1PairsFn)."""
     if norm_p != 1:
         raise NotImplementedError('norm_p=2 calls a non-existent F.rms_loss in the reference (Q13)')
     a = [m for fl in feat_sig_list for m in fl]
     b = [m.detach() for fl in feat_ref_list for m in fl]
-    return L1PairsFn.apply(len(a), *a, *b)
+    lo, hi = (0, None) if rng is None else (int(rng[0]), int(rng[1]))
+    return L1PairsFn.apply(len(a), lo, hi, *a, *b)
 
 
 # ------------------------------------------------------------------------------- log-mel

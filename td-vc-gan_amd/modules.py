@@ -404,9 +404,14 @@ def generator_forward_pair(G, x, x_other, conds, c_vars):
     emb = G.embedding(torch.cat([c.contiguous().float() for c in conds], dim=0))
     content = torch.cat([emb_x] * n, dim=0) if n > 1 else emb_x
     y, subs = G.decoder(content, emb, torch.cat(list(c_vars), dim=0) if n > 1 else c_vars[0], out_subsample=True)
-    outs = [(y[i * B:(i + 1) * B], [s_[i * B:(i + 1) * B] for s_ in subs]) for i in range(n)]
+    outs = _PairList((y[i * B:(i + 1) * B], [s_[i * B:(i + 1) * B] for s_ in subs]) for i in range(n))
+    outs.full = (y, subs)          # the batched tensors themselves ([cond 0; cond 1; ...] along the batch axis)
     G.content_embedding = emb_x
     return outs, emb_x, emb_other
+
+
+class _PairList(list):
+    """List of per-conditioning (y, subs) pairs that also carries the batched tensors they are slices of (`.full`)."""
 
 
 # ------------------------------------------------------------------------------- discriminator

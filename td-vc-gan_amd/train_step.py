@@ -112,6 +112,7 @@ class TrainStep:
                                                          conds, cvars)
         fake = outs[0]
         idt = outs[1] if want_idt else (fake if c.lambda_idt > 0 else None)
+        self._gen_full = outs.full if want_idt else None      # (y, subs) over [target; identity]: the D input of the G-step as is
         return fake, idt, emb_real, emb_cor
 
     def d_step(self, batch, log):
@@ -142,8 +143,7 @@ class TrainStep:
         l2 = torch.cat([batch['label_src'], batch['label_tgt']], dim=0)
         s2 = [torch.cat([r, f.detach()], dim=0) for r, f in zip(self._real_subs, fake_subs)]
         outs, _ = D(x2, l2, s2)
-        l_real = LS.lsgan_loss([o[:B] for o in outs], 1.0)
-        l_fake = LS.lsgan_loss([o[B:] for o in outs], 0.0)
+        l_real, l_fake = LS.lsgan_split(outs, B)          # both halves of the batched outputs, gradients written in place
         d_loss = l_real + l_fake
         self.opt_d.zero_grad()
         d_loss.backward()
@@ -187,22 +187,27 @@ class TrainStep:
                 sigs, subs, labels = [fake], [fake_subs], [batch['label_tgt']]
                 if separate_idt:
                     sigs.append(idt_pair[0]); subs.append(idt_pair[1]); labels.append(batch['label_src'])
+                    full = getattr(self, '_gen_full', None)
+                    if full is not None and self.reuse_fake:      # [fake; idt] IS the decoder's batched output: no re-concatenation
+                        sigs, subs = [full[0]], [full[1]]
                 if want_rec and c.lambda_feat > 0:
                     sigs.append(rec); subs.append(rec_subs); labels.append(batch['label_src'])
-                outs, feats = D(torch.cat(sigs, dim=0), torch.cat(labels, dim=0),
-                                [torch.cat([s_[i] for s_ in subs], dim=0) for i in range(len(fake_subs))])
-                out_fake = [o[:B] for o in outs]
-                feats_fake = [[m[:B] for m in fl] for fl in feats]
+                cat = lambda ts: ts[0] if len(ts) == 1 else torch.cat(ts, dim=0)
+                outs, feats = D(cat(sigs), torch.cat(labels, dim=0), [cat([s_[i] for s_ in subs]) for i in range(len(fake_subs))])
+                # the loss terms read their sample range of the BATCHED outputs / feature maps (losses.L1PairsFn)
+                out_fake, adv_rng = outs, (0, B)
                 pos = 1
                 idt, idt_subs = (fake, fake_subs) if idt_pair is not None else (None, None)
-                feats_idt = None
+                feats_idt = feats_rec = None
+                idt_rng = rec_rng = None
                 if separate_idt:
                     idt, idt_subs = idt_pair
-                    feats_idt = [[m[pos * B:(pos + 1) * B] for m in fl] for fl in feats]
+                    feats_idt, idt_rng = feats, (pos * B, (pos + 1) * B)
                     pos += 1
                 if want_rec and c.lambda_feat > 0:
-                    feats_rec = [[m[pos * B:(pos + 1) * B] for m in fl] for fl in feats]
+                    feats_rec, rec_rng = feats, (pos * B, (pos + 1) * B)
             else:
+                adv_rng = idt_rng = rec_rng = None
                 out_fake, feats_fake = D(fake, batch['label_tgt'], fake_subs)
                 idt, idt_subs = (fake, fake_subs) if idt_pair is not None else (None, None)
                 # no_conv: the identity signal IS the converted signal, but it is judged with label_src (train.py:374)
@@ -213,7 +218,7 @@ class TrainStep:
                         feats_idt = feats_fake
                     else:
                         _, feats_idt = D(idt, batch['label_src'], idt_subs)
-            adv = LS.lsgan_loss(out_fake, 1.0)
+            adv = LS.lsgan_loss(out_fake, 1.0, rng=adv_rng)
             total = adv
             log['G_loss_adv_fake'] = adv.detach()
             feats_real = None
@@ -223,7 +228,7 @@ class TrainStep:
             if want_rec:                                   # train.py:344-361
                 l_rec = None
                 if feats_rec is not None:
-                    l_rf = LS.multiscale_feat_loss(feats_rec, feats_real, norm_p=1)
+                    l_rf = LS.multiscale_feat_loss(feats_rec, feats_real, norm_p=1, rng=rec_rng)
                     log['G_loss_rec_feat'] = l_rf.detach()
                     l_rec = c.lambda_feat * l_rf
                 if c.lambda_spec > 0:
@@ -236,7 +241,7 @@ class TrainStep:
             if c.lambda_idt > 0 and idt is not None:
                 l_idt = None
                 if need_feat:
-                    l_feat = LS.multiscale_feat_loss(feats_idt, feats_real, norm_p=1)
+                    l_feat = LS.multiscale_feat_loss(feats_idt, feats_real, norm_p=1, rng=idt_rng)
                     log['G_loss_idt_feat'] = l_feat.detach()
                     l_idt = c.lambda_feat * l_feat
                 if c.lambda_spec > 0:
