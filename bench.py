@@ -83,7 +83,7 @@ def time_launches(torch, calls, iters):
     return e0.elapsed_time(e1) / iters
 
 
-def kernel_table(pkg, dev, B, step_ms, iters=40):
+def kernel_table(pkg, dev, B, step_ms, iters=40, manifest=None):
     """Per-kernel roofline table at the step's launch shapes (B samples per GPU -> every trunk conv sees BL = 2B:
     decoder [target; identity] conditionings, encoder [real; corrupted], discriminator [real; fake] / [fake; identity];
     discs 1 and 2 see another x2 from the batched sub-scale pass). `n` = launches of that (op, shape) per iteration of
@@ -105,6 +105,8 @@ def kernel_table(pkg, dev, B, step_ms, iters=40):
     def add(label, n, bound, alg_bytes, flops, calls, rot_bytes):
         name = traced(calls[0])
         ms = time_launches(torch, calls, iters)
+        if manifest is not None:      # tools/microbench_kernels.py: lets the PMC summary map dispatches back to this entry
+            manifest.append(dict(op=label, kernels=name.split(' + '), calls=1 + len(calls) + 2 + iters))
         ach_b, ach_f = alg_bytes / (ms * 1e-3) / 1e9, flops / (ms * 1e-3) / 1e12
         e = dict(kernel=name, op=label, launches_per_step=n, ms_per_launch=ms, share_of_step=n * ms / step_ms, bound=bound,
                  achieved=ach_b if bound == 'hbm' else ach_f, peak=HBM_PEAK_GBS if bound == 'hbm' else MFMA_F32_PEAK_TF,
@@ -276,12 +278,13 @@ def cpu_baseline(pkg, cfg_train, iters=3):
                        'generator forward like the reference does, anomaly detection off)')
 
 
-def pmc_traffic(name):
-    """HBM bytes per launch of kernel `name` from the committed rocprofv3 PMC passes of this round (separate
-    --pmc FETCH_SIZE / --pmc WRITE_SIZE runs, FETCH_SIZE doubled per MI355X_MICROARCH.md): profiles/r02_pmc_traffic.json."""
+def pmc_traffic(op):
+    """HBM bytes per launch of table entry `op` from the committed rocprofv3 PMC passes of this round (separate
+    --pmc FETCH_SIZE / --pmc WRITE_SIZE runs over tools/microbench_kernels.py = this very table; FETCH_SIZE doubled per
+    MI355X_MICROARCH.md): profiles/r02_pmc.json, written by tools/pmc_traffic.py. None when the entry is not in it."""
     try:
-        tab = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc_traffic.json')))
-        return tab.get('kernels', {}).get(name)
+        tab = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc.json')))
+        return tab.get('entries', {}).get(op, {}).get('hbm_bytes_per_launch')
     except (OSError, ValueError):
         return None
 
@@ -381,12 +384,12 @@ def main():
             dom = table[0]
             roof = {k: dom[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'kernel', 'op', 'ms_per_launch', 'launches_per_step',
                                         'share_of_step', 'algorithmic_bytes', 'algorithmic_flops')}
-            roof['traffic'] = pmc_traffic(dom['kernel'])
+            roof['traffic'] = pmc_traffic(dom['op'])
             roof['how'] = ('dominant kernel of the step by launches x measured time; HIP events on the launch stream over launches that rotate '
                            f'through {dom["rotation_bytes"] / 1e6:.0f} MB of operand sets (nothing served from the 256 MB Infinity Cache); '
                            'traffic = rocprofv3 PMC passes committed under profiles/ (null when absent)')
             # the kernel the north star names: stride-1 dilated Conv1d, 16 -> 16, k3 (HBM-bound end of the trunk)
-            roof['north_star_kernel'] = dict(north, traffic=pmc_traffic(north['kernel']))
+            roof['north_star_kernel'] = dict(north, traffic=pmc_traffic(north['op']))
             roof['kernels'] = [{k: e[k] for k in ('kernel', 'op', 'launches_per_step', 'ms_per_launch', 'share_of_step', 'bound', 'achieved',
                                                   'peak', 'unit', 'frac')} for e in table[:12]]
             roof['table_share_of_step'] = sum(e['share_of_step'] for e in table)

@@ -45,8 +45,11 @@ __device__ __forceinline__ float lean_fetch(const LeanP& p, int b, int c, int q)
   return lean_xform<XFK>(p, p.x[(long)b * p.x_bs + (long)c * p.T + q], b, c, q);
 }
 
+#ifndef LEAN_OCC_SMALL
+#define LEAN_OCC_SMALL 4      // resident blocks per CU asked for the 16-row tiles (A/B knob: make ab EXTRA=-DLEAN_OCC_SMALL=5)
+#endif
 template <int M_REP, int N_REP, int WM, int WN, int XFK, int EPI>
-__global__ __launch_bounds__(256, (M_REP * N_REP >= 12 ? 2 : ((M_REP * N_REP >= 8 || 16 * M_REP * WM >= 48) ? 3 : 4))) void conv_lean_kernel(const LeanP p) {
+__global__ __launch_bounds__(256, (M_REP * N_REP >= 12 ? 2 : ((M_REP * N_REP >= 8 || 16 * M_REP * WM >= 48) ? 3 : LEAN_OCC_SMALL))) void conv_lean_kernel(const LeanP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int MT = 16 * M_REP * WM, NT = 16 * N_REP * WN;
   constexpr int XVP = MT >= 32 ? 12 : 6;                  // max row-walk passes of the prefetched input tile

@@ -1,0 +1,40 @@
+"""bench.py's per-kernel roofline table as a standalone program, for rocprofv3 (kernel trace / PMC passes):
+
+    rocprofv3 --pmc FETCH_SIZE --kernel-trace --output-format csv -d gpurun_out/pmc_fetch -- \\
+        python3 tools/microbench_kernels.py --iters 6 --manifest gpurun_out/pmc_manifest.json
+
+Every entry launches the kernel(s) of one (op, launch shape) of the step on rotating operand sets; the manifest records, in
+launch order, which kernel names and how many calls belong to each entry so that tools/pmc_traffic.py can assign the
+profiler's per-dispatch counters back to the entries."""
+import argparse
+import importlib
+import json
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+import bench  # noqa: E402
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--iters', type=int, default=6)
+    ap.add_argument('--batch', type=int, default=16)
+    ap.add_argument('--manifest', default=os.path.join(ROOT, 'gpurun_out', 'pmc_manifest.json'))
+    a = ap.parse_args()
+    dev = torch.device('cuda:0')
+    torch.cuda.set_device(dev)
+    pkg = importlib.import_module('td-vc-gan_amd')
+    manifest = []
+    rows, _ = bench.kernel_table(pkg, dev, a.batch, 1.0, iters=a.iters, manifest=manifest)
+    os.makedirs(os.path.dirname(a.manifest), exist_ok=True)
+    json.dump(manifest, open(a.manifest, 'w'), indent=1)
+    for e in sorted(rows, key=lambda e: -e['ms_per_launch'] * e['launches_per_step']):
+        print(f"{e['ms_per_launch'] * 1e3:9.1f} us x{e['launches_per_step']:2d}  {e['frac']:.3f} of {e['bound']:4s} peak  {e['op']}  [{e['kernel']}]", flush=True)
+
+
+if __name__ == '__main__':
+    main()
