@@ -76,155 +76,175 @@ def cross_entropy_loss(logits, labels):
     return CrossEntropyFn.apply(logits, labels)
 
 
-def _rows(x, lo, hi):
-    """(byte offset, element count) of samples [lo, hi) of a batch-major contiguous tensor."""
-    per = x[0].numel()
-    return 4 * lo * per, (hi - lo) * per
+class BatchView:
+    """Samples [off, off + n) of a batch-major contiguous tensor `t`, WITHOUT materialising the slice.
+
+    The train step pushes several signals through the discriminator in one call (real | fake, fake | identity |
+    reconstruction, and inside discriminators 1 / 2 the filtered input | the sub-scale input on top). Every loss term
+    reads a sample range of those batched outputs / feature maps. Slicing them as tensors makes autograd run, for each
+    of the ~30 maps of up to 33 MB, a zero-fill of a full-size gradient, a copy of the slice gradient into it and an add
+    of the partial gradients (5 % of the iteration). The loss functions below take views instead and write ONE
+    full-size gradient per batched tensor: the kernels address the range through a pointer offset."""
+    __slots__ = ('t', 'off', 'n')
+
+    def __init__(self, t, off=0, n=None):
+        self.t, self.off, self.n = t, off, (t.shape[0] - off) if n is None else n
+
+    def rows(self, lo, hi):
+        assert 0 <= lo <= hi <= self.n
+        return BatchView(self.t, self.off + lo, hi - lo)
+
+    def tensor(self):
+        return self.t[self.off:self.off + self.n]
+
+    @property
+    def shape(self):
+        return (self.n, *self.t.shape[1:])
+
+    def detach(self):
+        return BatchView(self.t.detach(), self.off, self.n)
 
 
-def _zero_outside(dx, lo, hi, lib):
-    """Zero the rows of dx outside [lo, hi) (the loss does not see them)."""
-    N = dx.shape[0]
+def as_view(x):
+    return x if isinstance(x, BatchView) else BatchView(x)
+
+
+def _group(views):
+    """Unique underlying tensors of `views` (contiguous) and, per view, the index of its tensor."""
+    tensors, index, which = [], {}, []
+    for v in views:
+        k = id(v.t)
+        if k not in index:
+            index[k] = len(tensors)
+            tensors.append(v.t.contiguous())
+        which.append(index[k])
+    return tensors, which
+
+
+def _fill_gaps(dx, ranges, lib):
+    """Zero the rows of dx that none of the (off, n) ranges covers."""
+    per = dx[0].numel()
     st = _stream(dx)
-    if lo > 0:
-        off, n = _rows(dx, 0, lo)
-        L.check(lib.tdvc_fill(dx.data_ptr() + off, 0.0, n, st))
-    if hi < N:
-        off, n = _rows(dx, hi, N)
-        L.check(lib.tdvc_fill(dx.data_ptr() + off, 0.0, n, st))
+    pos = 0
+    for off, n in sorted(ranges):
+        if off > pos:
+            L.check(lib.tdvc_fill(dx.data_ptr() + 4 * pos * per, 0.0, (off - pos) * per, st))
+        pos = max(pos, off + n)
+    if pos < dx.shape[0]:
+        L.check(lib.tdvc_fill(dx.data_ptr() + 4 * pos * per, 0.0, (dx.shape[0] - pos) * per, st))
 
 
-class MseConstRangeFn(Function):
-    """sum_i mean((x_i[lo:hi] - target)^2): the LSGAN term on a sample range of BATCHED discriminator outputs. The
-    gradient is produced directly at full batch size (zero outside the range), so no slice copy / zero-pad / add kernels
-    appear in the backward pass."""
+class MseViewsFn(Function):
+    """LSGAN terms on views of batched discriminator outputs: spec = [(tensor index, off, n, target, k)]; returns
+    `nout` scalars, scalar k = sum over its entries of mean((x[off:off+n] - target)^2). One gradient per tensor."""
 
     @staticmethod
-    def forward(ctx, target, lo, hi, *xs):
-        xs = [x.contiguous() for x in xs]
-        out = _ScalarOut.new(xs[0])
+    def forward(ctx, spec, nout, *xs):
+        outs = [_ScalarOut.new(xs[0]) for _ in range(nout)]
         lib = L.lib()
-        for x in xs:
-            off, n = _rows(x, lo, hi)
-            L.check(lib.tdvc_mse_const_fwd(x.data_ptr() + off, n, target, 1.0, out.data_ptr(), _stream(x)))
-        ctx.args = (target, lo, hi)
+        for ti, off, n, target, k in spec:
+            x = xs[ti]
+            per = x[0].numel()
+            L.check(lib.tdvc_mse_const_fwd(x.data_ptr() + 4 * off * per, n * per, target, 1.0, outs[k].data_ptr(), _stream(x)))
+        ctx.spec = spec
         ctx.save_for_backward(*xs)
-        return out
+        return tuple(outs)
 
     @staticmethod
-    def backward(ctx, g):
-        target, lo, hi = ctx.args
-        g = g.contiguous()
-        lib = L.lib()
-        grads = []
-        for x in ctx.saved_tensors:
-            dx = torch.empty_like(x)
-            _zero_outside(dx, lo, hi, lib)
-            off, n = _rows(x, lo, hi)
-            L.check(lib.tdvc_mse_const_bwd(x.data_ptr() + off, n, target, 1.0, g.data_ptr(), dx.data_ptr() + off, _stream(x)))
-            grads.append(dx)
-        return (None, None, None, *grads)
-
-
-class LsganSplitFn(Function):
-    """D-step losses on outputs of ONE discriminator call over [real; fake] (train.py:271-281): returns
-    (sum_i mean((x_i[:B] - 1)^2), sum_i mean(x_i[B:]^2)) and writes both gradient halves into one tensor per output."""
-
-    @staticmethod
-    def forward(ctx, B, *xs):
-        xs = [x.contiguous() for x in xs]
-        l_real, l_fake = _ScalarOut.new(xs[0]), _ScalarOut.new(xs[0])
-        lib = L.lib()
-        for x in xs:
-            N = x.shape[0]
-            o0, n0 = _rows(x, 0, B)
-            o1, n1 = _rows(x, B, N)
-            L.check(lib.tdvc_mse_const_fwd(x.data_ptr() + o0, n0, 1.0, 1.0, l_real.data_ptr(), _stream(x)))
-            L.check(lib.tdvc_mse_const_fwd(x.data_ptr() + o1, n1, 0.0, 1.0, l_fake.data_ptr(), _stream(x)))
-        ctx.B = B
-        ctx.save_for_backward(*xs)
-        return l_real, l_fake
-
-    @staticmethod
-    def backward(ctx, g_real, g_fake):
-        lib = L.lib()
+    def backward(ctx, *gs):
         xs = ctx.saved_tensors
-        zero = None
-        if g_real is None or g_fake is None:
-            zero = torch.zeros(1, dtype=torch.float32, device=xs[0].device)
-        g_real = g_real.contiguous() if g_real is not None else zero
-        g_fake = g_fake.contiguous() if g_fake is not None else zero
+        lib = L.lib()
+        zero = torch.zeros(1, dtype=torch.float32, device=xs[0].device) if any(g is None for g in gs) else None
+        gs = [g.contiguous() if g is not None else zero for g in gs]
         grads = []
-        for x in xs:
+        for ti, x in enumerate(xs):
+            mine = [e for e in ctx.spec if e[0] == ti]
             dx = torch.empty_like(x)
-            o0, n0 = _rows(x, 0, ctx.B)
-            o1, n1 = _rows(x, ctx.B, x.shape[0])
-            L.check(lib.tdvc_mse_const_bwd(x.data_ptr() + o0, n0, 1.0, 1.0, g_real.data_ptr(), dx.data_ptr() + o0, _stream(x)))
-            L.check(lib.tdvc_mse_const_bwd(x.data_ptr() + o1, n1, 0.0, 1.0, g_fake.data_ptr(), dx.data_ptr() + o1, _stream(x)))
+            _fill_gaps(dx, [(off, n) for _, off, n, _, _ in mine], lib)
+            per = x[0].numel()
+            for _, off, n, target, k in mine:
+                L.check(lib.tdvc_mse_const_bwd(x.data_ptr() + 4 * off * per, n * per, target, 1.0, gs[k].data_ptr(),
+                                               dx.data_ptr() + 4 * off * per, _stream(x)))
             grads.append(dx)
-        return (None, *grads)
+        return (None, None, *grads)
 
 
 def lsgan_loss(outs, target, rng=None):
-    """rng = (lo, hi): the outputs are batched over several signals and only samples [lo, hi) enter this term."""
-    if rng is None:
-        return MseConstFn.apply(float(target), *outs)
-    return MseConstRangeFn.apply(float(target), int(rng[0]), int(rng[1]), *outs)
+    """sum_i mean((o_i - target)^2) (train.py:273-279, 327-331). `outs` may hold BatchViews; rng = (lo, hi) restricts every
+    output to samples [lo, hi) of its view (the outputs are batched over several signals)."""
+    views = [as_view(o) for o in outs]
+    if rng is not None:
+        views = [v.rows(int(rng[0]), int(rng[1])) for v in views]
+    tensors, which = _group(views)
+    spec = [(ti, v.off, v.n, float(target), 0) for ti, v in zip(which, views)]
+    return MseViewsFn.apply(spec, 1, *tensors)[0]
 
 
 def lsgan_split(outs, B):
-    """(real term on samples [0, B), fake term on samples [B, N)) of one batched discriminator call."""
-    return LsganSplitFn.apply(int(B), *outs)
+    """D-step pair (train.py:271-281) on outputs of ONE discriminator call over [real; fake]:
+    (sum_i mean((o_i[:B] - 1)^2), sum_i mean(o_i[B:]^2))."""
+    views = [as_view(o) for o in outs]
+    tensors, which = _group(views)
+    spec = []
+    for ti, v in zip(which, views):
+        spec.append((ti, v.off, B, 1.0, 0))
+        spec.append((ti, v.off + B, v.n - B, 0.0, 1))
+    return MseViewsFn.apply(spec, 2, *tensors)
 
 
-class L1PairsFn(Function):
-    """sum over pairs of mean|a[lo:hi] - b| (b carries no gradient). With a sample range the a's are BATCHED feature
-    maps (several signals through the discriminator in one call); their gradient comes out at full batch size, zero
-    outside the range — the slice / zero-pad / copy kernels autograd would otherwise run on 30 feature maps of up to
-    33 MB each were 4 % of the iteration."""
+class L1ViewsFn(Function):
+    """sum over pairs of mean|a[off:off+n] - b[roff:roff+n]| on views of batched feature maps (b carries no gradient):
+    spec = [(a tensor index, off, n, b tensor index, roff)]. One full-size gradient per batched `a` tensor."""
 
     @staticmethod
-    def forward(ctx, n, lo, hi, *ab):
-        a = [t.contiguous() for t in ab[:n]]
-        b = [t.contiguous() for t in ab[n:]]
+    def forward(ctx, spec, n_a, *ts):
+        a, b = ts[:n_a], ts[n_a:]
         out = _ScalarOut.new(a[0])
         lib = L.lib()
-        for x, y in zip(a, b):
-            h = x.shape[0] if hi is None else hi
-            if x[lo:h].shape != y.shape:
-                raise RuntimeError(f'l1 pair shape mismatch {tuple(x[lo:h].shape)} vs {tuple(y.shape)}')
-            off, cnt = _rows(x, lo, h)
-            L.check(lib.tdvc_l1_fwd(x.data_ptr() + off, y.data_ptr(), cnt, 1.0, out.data_ptr(), _stream(x)))
-        ctx.n, ctx.lo, ctx.hi = n, lo, hi
-        ctx.save_for_backward(*a, *b)
+        for ai, off, n, bi, roff in spec:
+            x, y = a[ai], b[bi]
+            if x.shape[1:] != y.shape[1:]:
+                raise RuntimeError(f'l1 pair shape mismatch {tuple(x.shape[1:])} vs {tuple(y.shape[1:])}')
+            per = x[0].numel()
+            L.check(lib.tdvc_l1_fwd(x.data_ptr() + 4 * off * per, y.data_ptr() + 4 * roff * per, n * per, 1.0, out.data_ptr(), _stream(x)))
+        ctx.spec, ctx.n_a = spec, n_a
+        ctx.save_for_backward(*ts)
         return out
 
     @staticmethod
     def backward(ctx, g):
         g = g.contiguous()
-        n = ctx.n
-        a, b = ctx.saved_tensors[:n], ctx.saved_tensors[n:]
+        a, b = ctx.saved_tensors[:ctx.n_a], ctx.saved_tensors[ctx.n_a:]
         lib = L.lib()
         grads = []
-        for x, y in zip(a, b):
-            h = x.shape[0] if ctx.hi is None else ctx.hi
+        for ai, x in enumerate(a):
+            mine = [e for e in ctx.spec if e[0] == ai]
             dx = torch.empty_like(x)
-            _zero_outside(dx, ctx.lo, h, lib)
-            off, cnt = _rows(x, ctx.lo, h)
-            L.check(lib.tdvc_l1_bwd(x.data_ptr() + off, y.data_ptr(), cnt, 1.0, g.data_ptr(), dx.data_ptr() + off, 0, _stream(x)))
+            _fill_gaps(dx, [(off, n) for _, off, n, _, _ in mine], lib)
+            per = x[0].numel()
+            for _, off, n, bi, roff in mine:
+                L.check(lib.tdvc_l1_bwd(x.data_ptr() + 4 * off * per, b[bi].data_ptr() + 4 * roff * per, n * per, 1.0, g.data_ptr(),
+                                        dx.data_ptr() + 4 * off * per, 0, _stream(x)))
             grads.append(dx)
-        return (None, None, None, *grads, *([None] * n))
+        return (None, None, *grads, *([None] * len(b)))
 
 
 def multiscale_feat_loss(feat_sig_list, feat_ref_list, norm_p=1, rng=None):
-    """util/losses.py:55-68. rng = (lo, hi): `feat_sig_list` holds feature maps of a discriminator call batched over
-    several signals and only samples [lo, hi) are the signal of this term (product-side extension, see L1PairsFn)."""
+    """util/losses.py:55-68: sum over the 5 passes x 6 maps of mean|sig - ref.detach()|. Maps may be BatchViews;
+    rng = (lo, hi) restricts every `sig` map to samples [lo, hi) of its view (product-side extension, see BatchView)."""
     if norm_p != 1:
         raise NotImplementedError('norm_p=2 calls a non-existent F.rms_loss in the reference (Q13)')
-    a = [m for fl in feat_sig_list for m in fl]
-    b = [m.detach() for fl in feat_ref_list for m in fl]
-    lo, hi = (0, None) if rng is None else (int(rng[0]), int(rng[1]))
-    return L1PairsFn.apply(len(a), lo, hi, *a, *b)
+    a = [as_view(m) for fl in feat_sig_list for m in fl]
+    b = [as_view(m).detach() for fl in feat_ref_list for m in fl]
+    if rng is not None:
+        a = [v.rows(int(rng[0]), int(rng[1])) for v in a]
+    for v, w in zip(a, b):
+        if v.n != w.n:
+            raise RuntimeError(f'l1 pair batch mismatch {v.n} vs {w.n}')
+    ta, wa = _group(a)
+    tb, wb = _group(b)
+    spec = [(ia, v.off, v.n, ib, w.off) for ia, v, ib, w in zip(wa, a, wb, b)]
+    return L1ViewsFn.apply(spec, len(ta), *ta, *tb)
 
 
 # ------------------------------------------------------------------------------- log-mel

@@ -450,11 +450,13 @@ class CollaborativeMultibandDiscriminator(ArenaModule):
         self.L = 129
         self.down = FixedFIR(kaiser_filter_odd(self.L, 0.5, 10), 1, 2, (self.L - 1) // 2)
 
-    def forward(self, x, label_tgt, subscales=[]):
+    def forward(self, x, label_tgt, subscales=[], views=False):
         """Returns (outs, features) in the reference's order: disc0@T, disc1@T/2, disc2@T/4, then the sub-scale
         passes disc2@sub[T/4], disc1@sub[T/2]. A discriminator that sees both a filtered and a sub-scale input of
         the same length runs them as ONE pass with the batch doubled (exact: D has no cross-sample op) — the
-        short, latency-bound layers get twice the work per launch."""
+        short, latency-bound layers get twice the work per launch.
+        views=True (train step): the two halves of such a pass are returned as losses.BatchView objects on the
+        batched tensors instead of tensor slices, so that the loss terms produce one gradient per batched tensor."""
         self.begin_forward(x)
         x = x.contiguous().float()
         n = len(self.discriminators)
@@ -469,8 +471,13 @@ class CollaborativeMultibandDiscriminator(ArenaModule):
         for i, disc in enumerate(self.discriminators):
             if i in subs and subs[i].shape == xs[i].shape:
                 o, f = disc(torch.cat([xs[i], subs[i]], dim=0), torch.cat([label_tgt, label_tgt], dim=0))
-                main[i] = (o[:B], [m[:B] for m in f])
-                extra[i] = (o[B:], [m[B:] for m in f])
+                if views:
+                    from .losses import BatchView
+                    main[i] = (BatchView(o, 0, B), [BatchView(m, 0, B) for m in f])
+                    extra[i] = (BatchView(o, B, B), [BatchView(m, B, B) for m in f])
+                else:
+                    main[i] = (o[:B], [m[:B] for m in f])
+                    extra[i] = (o[B:], [m[B:] for m in f])
             else:
                 main[i] = disc(xs[i], label_tgt)
                 if i in subs:

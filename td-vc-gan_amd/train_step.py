@@ -142,7 +142,7 @@ class TrainStep:
         x2 = torch.cat([real, fake.detach()], dim=0)
         l2 = torch.cat([batch['label_src'], batch['label_tgt']], dim=0)
         s2 = [torch.cat([r, f.detach()], dim=0) for r, f in zip(self._real_subs, fake_subs)]
-        outs, _ = D(x2, l2, s2)
+        outs, _ = D(x2, l2, s2, views=True)
         l_real, l_fake = LS.lsgan_split(outs, B)          # both halves of the batched outputs, gradients written in place
         d_loss = l_real + l_fake
         self.opt_d.zero_grad()
@@ -193,8 +193,8 @@ class TrainStep:
                 if want_rec and c.lambda_feat > 0:
                     sigs.append(rec); subs.append(rec_subs); labels.append(batch['label_src'])
                 cat = lambda ts: ts[0] if len(ts) == 1 else torch.cat(ts, dim=0)
-                outs, feats = D(cat(sigs), torch.cat(labels, dim=0), [cat([s_[i] for s_ in subs]) for i in range(len(fake_subs))])
-                # the loss terms read their sample range of the BATCHED outputs / feature maps (losses.L1PairsFn)
+                outs, feats = D(cat(sigs), torch.cat(labels, dim=0), [cat([s_[i] for s_ in subs]) for i in range(len(fake_subs))], views=True)
+                # the loss terms read their sample range of the BATCHED outputs / feature maps (losses.BatchView)
                 out_fake, adv_rng = outs, (0, B)
                 pos = 1
                 idt, idt_subs = (fake, fake_subs) if idt_pair is not None else (None, None)
@@ -208,7 +208,7 @@ class TrainStep:
                     feats_rec, rec_rng = feats, (pos * B, (pos + 1) * B)
             else:
                 adv_rng = idt_rng = rec_rng = None
-                out_fake, feats_fake = D(fake, batch['label_tgt'], fake_subs)
+                out_fake, feats_fake = D(fake, batch['label_tgt'], fake_subs, views=True)
                 idt, idt_subs = (fake, fake_subs) if idt_pair is not None else (None, None)
                 # no_conv: the identity signal IS the converted signal, but it is judged with label_src (train.py:374)
                 feats_idt = None
@@ -217,14 +217,14 @@ class TrainStep:
                     if c.no_conv:
                         feats_idt = feats_fake
                     else:
-                        _, feats_idt = D(idt, batch['label_src'], idt_subs)
+                        _, feats_idt = D(idt, batch['label_src'], idt_subs, views=True)
             adv = LS.lsgan_loss(out_fake, 1.0, rng=adv_rng)
             total = adv
             log['G_loss_adv_fake'] = adv.detach()
             feats_real = None
             if (need_feat and idt is not None) or feats_rec is not None:
                 with torch.no_grad():                      # Q6: D(real) feature maps are only ever used detached
-                    _, feats_real = D(real, batch['label_src'], self._real_subs)
+                    _, feats_real = D(real, batch['label_src'], self._real_subs, views=True)
             if want_rec:                                   # train.py:344-361
                 l_rec = None
                 if feats_rec is not None:
