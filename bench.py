@@ -281,11 +281,13 @@ def cpu_baseline(pkg, cfg_train, iters=3):
 def pmc_traffic(op):
     """HBM bytes per launch of table entry `op` from the committed rocprofv3 PMC passes of this round (separate
     --pmc FETCH_SIZE / --pmc WRITE_SIZE runs over tools/microbench_kernels.py = this very table; FETCH_SIZE doubled per
-    MI355X_MICROARCH.md): profiles/r02_pmc.json, written by tools/pmc_traffic.py. None when the entry is not in it."""
+    MI355X_MICROARCH.md): the latest profiles/r*_pmc.json, written by tools/pmc_traffic.py. None when the entry is not in it."""
+    import glob
     try:
-        tab = json.load(open(os.path.join(ROOT, 'profiles', 'r02_pmc.json')))
+        files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc.json')))
+        tab = json.load(open(files[-1]))
         return tab.get('entries', {}).get(op, {}).get('hbm_bytes_per_launch')
-    except (OSError, ValueError):
+    except (OSError, ValueError, IndexError):
         return None
 
 

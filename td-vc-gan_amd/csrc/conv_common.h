@@ -24,6 +24,7 @@
 namespace tdvc {
 extern int g_trace_on;
 extern int g_force_tile;
+extern int g_lds_cap;
 void trace_kernel(const void* fn);
 }
 #define TDVC_TRACE(k) do { if (tdvc::g_trace_on) tdvc::trace_kernel(reinterpret_cast<const void*>(k)); } while (0)

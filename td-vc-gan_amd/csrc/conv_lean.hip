@@ -543,7 +543,7 @@ hipError_t launch_conv_lean_cond(LeanP p, int B, hipStream_t st) {
     return (size_t)(cc * p.XS + p.wnp * p.wrp * p.WS + p.Cv * p.ES + cc * 25) * sizeof(float);
   };
   size_t lds = geom(Cc);
-  if (lds > 80 * 1024 || p.wnp > (MT >= 48 ? 10 : 6)) lds = geom(Cc = 16);
+  if (lds > (size_t)(g_lds_cap > 0 ? g_lds_cap : 80 * 1024) || p.wnp > (MT >= 48 ? 10 : 6)) lds = geom(Cc = 16);
   dim3 grid((p.T + NT - 1) / NT, (p.Cout + MT - 1) / MT, B);
   if (MT == 32) {
     auto k = conv_lean_kernel<2, 4, 1, 4, LXF_COND, EPI_FWD>;
@@ -594,7 +594,7 @@ hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st) {
     walk_geometry(cc, p.span / 4, &xrp, &xnp);
     walk_geometry(MT, p.K * cc / 4, &wrp, &wnp);
     const size_t lds = (size_t)(xnp * xrp * p.XS + wnp * wrp * (p.K * cc + 2)) * 4;
-    if (lds > 64 * 1024 || wnp > wvp || (xfk == LXF_ACT && xnp > xvp)) continue;
+    if (lds > (size_t)(g_lds_cap > 0 ? g_lds_cap : 64 * 1024) || wnp > wvp || (xfk == LXF_ACT && xnp > xvp)) continue;
     Cc = cc; p.xrp = xrp; p.xnp = xnp; p.wrp = wrp; p.wnp = wnp;
   }
   if (!Cc) return hipErrorNotSupported;                  // weight tile would not fit the register prefetch
