@@ -54,6 +54,7 @@ struct GemmConvP {
   int i0;                       // staged index read by column n0, tap 0 (= first tap position - lo)
   int mirror_pad;               // > 0: fold reflect-pad halo (dgrad of a reflect conv)
   int stage_rows;               // DOWN with a large stride: stage with lanes along the reduced rows
+  int chan_stage;               // DOWN, chunk = whole channels (Cc % s == 0): coalesced time-to-depth staging per channel
   int w_nat;                    // weight rows are contiguous over (c,k) and float4-alignable (host-checked)
   float* y; long y_bs; int Ty; int Cy_g;
   int epi;

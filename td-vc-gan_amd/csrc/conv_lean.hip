@@ -588,13 +588,17 @@ hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st) {
   p.span = ((NT + hi - lo) + 3) / 4 * 4;
   p.XS = ((p.span + 31) / 32) * 32 + 16;
   const int xvp = MT >= 32 ? 12 : 6, wvp = MT >= 48 ? 10 : (MT >= 32 ? 6 : 4);   // = the kernel's XVP / WVP
+  // LDS budget per block = what lets the blocks the register budget allows (launch_bounds of the instance) actually be
+  // resident on a CU with 160 KB: 3 blocks for the 32-row x 256-column tile -> 52 KB (with 64 KB only two fit and the
+  // kernel ran 22 % slower: tools/tile_sweep.py), 64 KB for the 2-blocks-per-CU tiles and the narrow ones.
+  const size_t lds_cap = g_lds_cap > 0 ? (size_t)g_lds_cap : (size_t)((MT == 32 && NT == 256) ? 52 : 64) * 1024;
   int Cc = 0;
   for (int cc = 4; cc <= 32 && cc <= ((p.Cin + 3) / 4) * 4; cc += 4) {
     int xrp, xnp, wrp, wnp;
     walk_geometry(cc, p.span / 4, &xrp, &xnp);
     walk_geometry(MT, p.K * cc / 4, &wrp, &wnp);
     const size_t lds = (size_t)(xnp * xrp * p.XS + wnp * wrp * (p.K * cc + 2)) * 4;
-    if (lds > (size_t)(g_lds_cap > 0 ? g_lds_cap : 64 * 1024) || wnp > wvp || (xfk == LXF_ACT && xnp > xvp)) continue;
+    if (lds > lds_cap || wnp > wvp || (xfk == LXF_ACT && xnp > xvp)) continue;
     Cc = cc; p.xrp = xrp; p.xnp = xnp; p.wrp = wrp; p.wnp = wnp;
   }
   if (!Cc) return hipErrorNotSupported;                  // weight tile would not fit the register prefetch

@@ -144,6 +144,25 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 3 : 4)) void conv_gemm_
         }
         xs[r * p.XS + i] = v;
       }
+    } else if (MODE == MODE_DOWN && p.chan_stage) {
+      // Coalesced time-to-depth: the s phase rows (c, 0..s-1) of one channel are the SAME contiguous run of span*s
+      // samples x[c][(n0+lo)*s - pad ...], so consecutive lanes read consecutive samples (one wide coalesced stream per
+      // channel instead of s stride-s gathers) and the de-interleave happens on the way into LDS: sample e of the run
+      // belongs to phase e % s, column e / s.
+      const int nch = p.Cc / p.s, len = p.span * p.s;
+      const long qbase = (long)(n0 + p.lo) * p.s - p.pad;
+      const float inv_s = 1.0f / (float)p.s;
+      for (int ch = 0; ch < nch; ++ch) {
+        const int cr = c0 + ch * p.s;
+        const bool rv = cr < p.Cred;
+        const int chan = g * p.x.Cg + cr / p.s;
+        float* rows = xs + ch * p.s * p.XS;
+        for (int e = tid; e < len; e += 256) {
+          const int i = (int)(((float)e + 0.5f) * inv_s);
+          const int phi = e - i * p.s;
+          rows[phi * p.XS + i] = rv ? fetch_opnd(p.x, b, chan, (int)(qbase + e), 0, Cx_tot) : 0.f;
+        }
+      }
     } else if (!PIPE && fast_tile) {
       stage_rows_batched<4>(p.x, xs, p.XS, b, g * p.x.Cg + c0, min(p.Cc, p.Cred - c0), p.Cc, n0 + p.lo, p.span, Cx_tot, tid);
     } else {
@@ -349,6 +368,22 @@ __global__ __launch_bounds__(256, (M_REP * J >= 14 ? 3 : 4)) void conv_wgrad_ker
     }
     if (MODE != MODE_DOWN && rows_fast_ok(p.x, nc0 + p.lo, p.span)) {
       stage_rows_batched<8>(p.x, xs, p.XS, b, g * p.x.Cg + c0, min(16, p.Cred - c0), 16, nc0 + p.lo, p.span, Cx_tot, tid);
+    } else if (MODE == MODE_DOWN && (16 % p.s) == 0) {
+      // coalesced time-to-depth (see conv_gemm_kernel): the 16 reduced rows are 16/s whole channels
+      const int nch = 16 / p.s, len = p.span * p.s;
+      const long qbase = (long)(nc0 + p.lo) * p.s - p.pad;
+      const float inv_s = 1.0f / (float)p.s;
+      for (int chi = 0; chi < nch; ++chi) {
+        const int cr = c0 + chi * p.s;
+        const bool rv = cr < p.Cred;
+        const int chan = g * p.x.Cg + cr / p.s;
+        float* rows = xs + chi * p.s * p.XS;
+        for (int e = tid; e < len; e += 256) {
+          const int i = (int)(((float)e + 0.5f) * inv_s);
+          const int phi = e - i * p.s;
+          rows[phi * p.XS + i] = rv ? fetch_opnd(p.x, b, chan, (int)(qbase + e), 0, Cx_tot) : 0.f;
+        }
+      }
     } else {
       for (int r = wave; r < 16; r += 4) {
         const int cr = c0 + r;
@@ -531,6 +566,13 @@ hipError_t launch_conv_gemm(GemmConvP p, int B, hipStream_t st) {
     // keep the chunk inside the kernels' register-prefetch budgets (8 float4 of input, 24/36 weights per thread)
     if (Cc >= 8 && ((long)next * (p.span >> 2) > 8 * 256 || (long)MT * p.J * next > (MT >= 64 ? 10 : 6) * 1024)) break;
     Cc = next;
+  }
+  p.chan_stage = 0;
+  if (MODE == MODE_DOWN && !p.stage_rows) {   // whole channels per chunk -> coalesced time-to-depth staging (kernel)
+    int unit_s = p.s;                         // lcm(4, s)
+    while (unit_s % 4) unit_s += p.s;
+    if (Cc >= unit_s) { Cc = Cc / unit_s * unit_s; p.chan_stage = 1; }
+    else if (((p.Cred + 3) / 4) * 4 == Cc && Cc % p.s == 0) p.chan_stage = 1;   // the whole reduction in one chunk
   }
   p.Cc = Cc;
   p.WS = p.J * Cc + 2;                      // WS/2 odd: 16 rows x 2 k-lanes hit 32 distinct banks (odd J)

@@ -7,6 +7,7 @@ the end of the backward pass — folds them into (weight_v, weight_g) gradients.
 per-tensor accumulate launches per iteration.
 """
 import ctypes as C
+import os
 
 import torch
 from torch.autograd import Function
@@ -233,6 +234,9 @@ class FilmBlockFn(Function):
         return dx, dgb, (d_out if ctx.has_acc else None), None, None, None, None
 
 
+FUSED_COND_FWD = os.environ.get('TDVC_FUSED_COND_FWD', '0') == '1'     # single-launch conditioning forward (tdvc_film_cond_fwd)
+
+
 class FilmCondFn(Function):
     """gb = cond_var.2(LeakyReLU(cond_var.0([emb; exc]))) (model/generator.py:86-92,103) in one forward launch:
     the time-constant embedding part enters as k3 [B,nc,3], the excitation part of cond_var.0 is an MFMA pre-pass
@@ -244,11 +248,18 @@ class FilmCondFn(Function):
         exc, k3 = exc.contiguous(), k3.contiguous()
         B, nv, T = exc.shape
         nc = spec2.cin
-        cv0 = torch.empty((B, nc, T), dtype=torch.float32, device=exc.device)
-        gb = torch.empty((B, spec2.cout, T), dtype=torch.float32, device=exc.device)
-        a = L.FilmCondArgs(B, T, nc, nv, spec2.cout, exc.data_ptr(), _bs(exc), spec_var.slot.w, k3.data_ptr(),
-                           spec2.slot.w, spec2.slot.b or None, cv0.data_ptr(), _bs(cv0), gb.data_ptr(), _bs(gb), SLOPE)
-        L.check(L.lib().tdvc_film_cond_fwd(C.byref(a), _stream(exc)))
+        if FUSED_COND_FWD:
+            cv0 = torch.empty((B, nc, T), dtype=torch.float32, device=exc.device)
+            gb = torch.empty((B, spec2.cout, T), dtype=torch.float32, device=exc.device)
+            a = L.FilmCondArgs(B, T, nc, nv, spec2.cout, exc.data_ptr(), _bs(exc), spec_var.slot.w, k3.data_ptr(),
+                               spec2.slot.w, spec2.slot.b or None, cv0.data_ptr(), _bs(cv0), gb.data_ptr(), _bs(gb), SLOPE)
+            L.check(L.lib().tdvc_film_cond_fwd(C.byref(a), _stream(exc)))
+        else:
+            # two launches: the 8-channel excitation window of cond_var.0 (HBM-bound, writes the 136-channel intermediate
+            # once) and cond_var.2 on it with LeakyReLU-on-load. Measured faster than the single fused launch at every
+            # decoder stage once the plain kernel runs 3 blocks per CU (tools/tile_sweep.py).
+            cv0 = conv_fwd_raw(spec_var, exc, _xf(), bias3=k3)
+            gb = conv_fwd_raw(spec2, cv0, _xf(L.XF_LRELU))
         ctx.sv, ctx.s2 = spec_var, spec2
         ctx.save_for_backward(exc, cv0)
         return gb

@@ -205,11 +205,18 @@ def film_block_errors(cfg, dev, B=2):
 
 
 @pytest.mark.parametrize('cfg', [(16, 2048, 2), (64, 600, 3), (128, 260, 2), (32, 64, 2)], ids=['C16_T2048', 'C64_T600', 'C128_T260', 'C32_T64'])
-def test_film_conditioning_fused(cfg, dev):
+@pytest.mark.parametrize('fused_fwd', [False, True], ids=['fwd2launch', 'fwd1launch'])
+def test_film_conditioning_fused(cfg, fused_fwd, dev):
     """tdvc_film_cond_fwd / tdvc_film_cond0_bwd (FiLM conditioning path of model/generator.py:86-92,103 in the split
     formulation) against float64 autograd of the dense reference formulation
         gb = cond_var.2(LeakyReLU(cond_var.0(cat([emb.repeat(T), exc]))))."""
-    errs = film_cond_errors(cfg, dev)
+    ops = _mods()[0]
+    old = ops.FUSED_COND_FWD
+    ops.FUSED_COND_FWD = fused_fwd
+    try:
+        errs = film_cond_errors(cfg, dev)
+    finally:
+        ops.FUSED_COND_FWD = old
     assert max(errs.values()) < TOL, errs
 
 

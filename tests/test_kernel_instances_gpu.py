@@ -169,10 +169,19 @@ def test_launch_shape_conv(case, B, dev):
 LAUNCH_COND = [(16, 16000, 16), (32, 8000, 16), (64, 4000, 16), (128, 500, 32)]
 
 
+@pytest.mark.parametrize('fused_fwd', [False, True], ids=['fwd2launch', 'fwd1launch'])
 @pytest.mark.parametrize('cfg', LAUNCH_COND, ids=[f'C{c}_T{t}_B{b}' for c, t, b in LAUNCH_COND])
-def test_launch_shape_fused_conditioning(cfg, dev):
-    with traced() as tr:
-        errs = OPS.film_cond_errors(cfg, dev)
+def test_launch_shape_fused_conditioning(cfg, fused_fwd, dev):
+    """FiLM conditioning path (ops.FilmCondFn): forward as the two-launch default and as the single fused launch
+    (tdvc_film_cond_fwd, prologue kind LXF_COND), backward = the one-pass tdvc_film_cond0_bwd in both."""
+    ops = importlib.import_module('td-vc-gan_amd').ops
+    old = ops.FUSED_COND_FWD
+    ops.FUSED_COND_FWD = fused_fwd
+    try:
+        with traced() as tr:
+            errs = OPS.film_cond_errors(cfg, dev)
+    finally:
+        ops.FUSED_COND_FWD = old
     assert max(errs.values()) < TOL, (errs, sorted(tr.names))
-    assert any(n.startswith('conv_lean_kernel') and n.endswith(',4,0>') for n in tr.names), sorted(tr.names)
+    assert any(n.startswith('conv_lean_kernel') and n.endswith(',4,0>') for n in tr.names) == fused_fwd, sorted(tr.names)
     assert 'film_cond0_bwd_kernel' in tr.names, sorted(tr.names)

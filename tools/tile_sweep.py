@@ -18,9 +18,9 @@ dev = torch.device('cuda:0')
 BL = 32
 
 
-def conv_calls(cin, cout, T, which, pre=1):
-    spec = ops.ConvSpec(cin, cout, 3, 1, 1, 1, 1, False)
-    w = torch.randn(cout, cin, 3, device=dev) / (cin * 3) ** 0.5
+def conv_calls(cin, cout, T, which, pre=1, k=3, BL=BL):
+    spec = ops.ConvSpec(cin, cout, k, 1, (k - 1) // 2, 1, 1, False)
+    w = torch.randn(cout, cin, k, device=dev) / (cin * k) ** 0.5
     b = torch.randn(cout, device=dev) * 0.1
     wt = w.permute(1, 0, 2).contiguous()
     spec.slot = arena.ConvSlot(w.data_ptr(), b.data_ptr(), 0, 0, False, None, wt.data_ptr())
@@ -51,12 +51,18 @@ def cond_calls(C2, T):
 
 def main():
     stages = [(32, 16000), (64, 8000), (128, 4000), (256, 500)]
-    for C2, T in stages:
-        for which in ('fwd', 'dgrad', 'cond'):
-            calls, keep = cond_calls(C2, T) if which == 'cond' else conv_calls(136, C2, T, which)
+    jobs = [(136, C2, T, w, 3, BL) for C2, T in stages for w in ('fwd', 'dgrad', 'cond')]
+    if len(sys.argv) > 1 and sys.argv[1] == 'trunk':
+        jobs = [(1024, 1024, 63, 'fwd', 5, 64), (1024, 1024, 63, 'dgrad', 5, 64), (1024, 1024, 32, 'fwd', 5, 64),
+                (64, 64, 4000, 'fwd', 7, 32), (64, 64, 4000, 'dgrad', 7, 32), (128, 128, 500, 'fwd', 7, 32), (128, 128, 500, 'dgrad', 7, 32),
+                (32, 32, 8000, 'fwd', 7, 32), (32, 32, 8000, 'dgrad', 7, 32), (32, 32, 8000, 'fwd', 1, 32), (64, 64, 4000, 'fwd', 1, 32),
+                (8, 136, 16000, 'fwd', 3, 32), (8, 136, 4000, 'fwd', 3, 32), (256, 256, 50, 'fwd', 7, 32)]
+    for cin, C2, T, which, k, bl in jobs:
+        if True:
+            calls, keep = cond_calls(C2, T) if which == 'cond' else conv_calls(cin, C2, T, which, k=k, BL=bl)
             res = []
             for cap in (0, 52 * 1024, 40 * 1024):
-                for cfg in ((-1,) if which == 'cond' else (-1, 0, 1, 2, 5)):
+                for cfg in ((-1,) if which == 'cond' else (-1, 0, 1, 2, 4, 5, 6)):
                     lib.tdvc_debug_lds_cap(cap); lib.tdvc_debug_force_tile(cfg)
                     lib.tdvc_debug_trace(1)
                     try:
@@ -70,7 +76,7 @@ def main():
                     ms = bench.time_launches(torch, calls, 30)
                     res.append((cap, cfg, ms, name))
             lib.tdvc_debug_lds_cap(0); lib.tdvc_debug_force_tile(-1)
-            print(f'== 136->{C2} T={T} {which}', flush=True)
+            print(f'== {cin}->{C2} k{k} T={T} B={bl} {which}', flush=True)
             for cap, cfg, ms, name in res:
                 print(f'   cap={cap // 1024:3d}K tile={cfg:2d}  ' + (f'{ms * 1e3:8.1f} us  {name}' if ms is not None else f'FAILED {name}'), flush=True)
             del calls, keep
