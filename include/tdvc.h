@@ -115,7 +115,6 @@ size_t tdvc_conv_wgrad_workspace(const tdvc_conv_desc* d);
  *   instantiations launched; tdvc_debug_trace_dump copies them ('\n'-separated, NUL-terminated) and returns the size needed. */
 void tdvc_set_force_generic(int on);
 void tdvc_debug_force_tile(int cfg);
-void tdvc_debug_lean_db(int mask);    /* bit i: lean tile configuration i uses the software-pipelined main loop (default 0x36) */
 void tdvc_debug_lds_cap(int bytes);   /* tuning knob: LDS bytes per block the lean kernel's chunk-size choice may use (0 = built-in) */
 void tdvc_debug_trace(int on);
 size_t tdvc_debug_trace_dump(char* buf, size_t cap);

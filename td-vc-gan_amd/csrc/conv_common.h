@@ -25,7 +25,6 @@ namespace tdvc {
 extern int g_trace_on;
 extern int g_force_tile;
 extern int g_lds_cap;
-extern int g_lean_db_mask;
 void trace_kernel(const void* fn);
 }
 #define TDVC_TRACE(k) do { if (tdvc::g_trace_on) tdvc::trace_kernel(reinterpret_cast<const void*>(k)); } while (0)

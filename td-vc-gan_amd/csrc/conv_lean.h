@@ -24,6 +24,5 @@ struct LeanP {
 
 hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st);
 hipError_t launch_conv_lean_cond(LeanP p, int B, hipStream_t st);
-hipError_t launch_conv_lean_db(const LeanP& p, int B, int cfg, int epi, hipStream_t st);   // conv_lean_db.hip
 
 }  // namespace tdvc

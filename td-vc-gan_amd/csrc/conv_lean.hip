@@ -45,17 +45,11 @@ __device__ __forceinline__ float lean_fetch(const LeanP& p, int b, int c, int q)
   return lean_xform<XFK>(p, p.x[(long)b * p.x_bs + (long)c * p.T + q], b, c, q);
 }
 
-#ifndef LEAN_OCC_16
-#define LEAN_OCC_16 4         // resident blocks per CU asked of the 16-row tiles with the plain prologue (A/B knob: -DLEAN_OCC_16=5)
+#ifndef LEAN_OCC_SMALL
+#define LEAN_OCC_SMALL 4      // resident blocks per CU asked for the 16-row tiles (A/B knob: make ab EXTRA=-DLEAN_OCC_SMALL=5)
 #endif
-// Blocks per CU the register allocation is budgeted for: 2 for the 48/64-row x 256 tiles, 3 for 32 x 256 and 64 x 64,
-// 4 (or LEAN_OCC_16) for the 16-row tiles. The host sizes the LDS tiles to match (launch_conv_lean).
-template <int M_REP, int N_REP, int WM, int XFK>
-constexpr int lean_min_blocks() {
-  return M_REP * N_REP >= 12 ? 2 : ((M_REP * N_REP >= 8 || 16 * M_REP * WM >= 48) ? 3 : ((16 * M_REP * WM == 16 && XFK == LXF_ACT) ? LEAN_OCC_16 : 4));
-}
 template <int M_REP, int N_REP, int WM, int WN, int XFK, int EPI>
-__global__ __launch_bounds__(256, (lean_min_blocks<M_REP, N_REP, WM, XFK>())) void conv_lean_kernel(const LeanP p) {
+__global__ __launch_bounds__(256, (M_REP * N_REP >= 12 ? 2 : ((M_REP * N_REP >= 8 || 16 * M_REP * WM >= 48) ? 3 : LEAN_OCC_SMALL))) void conv_lean_kernel(const LeanP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int MT = 16 * M_REP * WM, NT = 16 * N_REP * WN;
   constexpr int XVP = MT >= 32 ? 12 : 6;                  // max row-walk passes of the prefetched input tile
@@ -582,9 +576,6 @@ hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st) {
     MT = c.MT; NT = c.NT; cfg = c.cfg;
     if (blocks >= 512) break;
   }
-  // a tiny reduction (the 8-channel excitation window of cond_var.0: Cin*K = 24) makes the conv a pure HBM stream of its
-  // output: the 16-row tile keeps the most blocks resident (94 vs 111 us for 8 -> 136, T = 16000, 32 samples)
-  if ((long)p.Cin * p.K <= 48 && p.T > 80 && p.mirror == 0) { MT = 16; NT = 256; cfg = 0; }
   if (g_force_tile >= 0) {   // test-only (tdvc_debug_force_tile): pin the tile so that small shapes reach every instance
     for (const Cand& c : cands)
       if (c.cfg == g_force_tile) { MT = c.MT; NT = c.NT; cfg = c.cfg; }
@@ -598,28 +589,21 @@ hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st) {
   p.XS = ((p.span + 31) / 32) * 32 + 16;
   const int xvp = MT >= 32 ? 12 : 6, wvp = MT >= 48 ? 10 : (MT >= 32 ? 6 : 4);   // = the kernel's XVP / WVP
   // LDS budget per block = what lets the blocks the register budget allows (launch_bounds of the instance) actually be
-  // resident on a CU with 160 KB: 3 blocks -> 52 KB. With 64 KB only two 32-row x 256-column blocks fit and that kernel
-  // ran 22 % slower; the other tiles gain 0-6 % (tools/tile_sweep.py, profiles/r02_b_tile_sweep.txt).
-  const size_t lds_cap = g_lds_cap > 0 ? (size_t)g_lds_cap : (size_t)52 * 1024;
-  // the MFMA-bound tiles with the plain prologue run the software-pipelined main loop (conv_lean_db.hip: two LDS
-  // stages, one barrier per chunk, staging interleaved with the MFMAs) unless switched off (tdvc_debug_lean_db)
-  bool db = xfk == LXF_ACT && (cfg == 1 || cfg == 2 || cfg == 4 || cfg == 5) && ((g_lean_db_mask >> cfg) & 1);
+  // resident on a CU with 160 KB: 3 blocks for the 32-row x 256-column tile -> 52 KB (with 64 KB only two fit and the
+  // kernel ran 22 % slower: tools/tile_sweep.py), 64 KB for the 2-blocks-per-CU tiles and the narrow ones.
+  const size_t lds_cap = g_lds_cap > 0 ? (size_t)g_lds_cap : (size_t)((MT == 32 && NT == 256) ? 52 : 64) * 1024;
   int Cc = 0;
-  for (int pass = 0; pass < 2 && !Cc; ++pass) {
-    if (pass == 1) { if (!db) break; db = false; }          // no chunk size fits two stages: single-stage kernel
-    for (int cc = 4; cc <= 32 && cc <= ((p.Cin + 3) / 4) * 4; cc += 4) {
-      int xrp, xnp, wrp, wnp;
-      walk_geometry(cc, p.span / 4, &xrp, &xnp);
-      walk_geometry(MT, p.K * cc / 4, &wrp, &wnp);
-      const size_t lds = (size_t)(xnp * xrp * p.XS + wnp * wrp * (p.K * cc + 2) + 3) * 4 * (db ? 2 : 1);
-      if (lds > lds_cap || wnp > wvp || (xfk == LXF_ACT && xnp > xvp)) continue;
-      Cc = cc; p.xrp = xrp; p.xnp = xnp; p.wrp = wrp; p.wnp = wnp;
-    }
+  for (int cc = 4; cc <= 32 && cc <= ((p.Cin + 3) / 4) * 4; cc += 4) {
+    int xrp, xnp, wrp, wnp;
+    walk_geometry(cc, p.span / 4, &xrp, &xnp);
+    walk_geometry(MT, p.K * cc / 4, &wrp, &wnp);
+    const size_t lds = (size_t)(xnp * xrp * p.XS + wnp * wrp * (p.K * cc + 2)) * 4;
+    if (lds > lds_cap || wnp > wvp || (xfk == LXF_ACT && xnp > xvp)) continue;
+    Cc = cc; p.xrp = xrp; p.xnp = xnp; p.wrp = wrp; p.wnp = wnp;
   }
   if (!Cc) return hipErrorNotSupported;                  // weight tile would not fit the register prefetch
   p.Cc = Cc;
   p.WS = p.K * Cc + 2;
-  if (db) return launch_conv_lean_db(p, B, cfg, epi, st);
   switch (cfg) {
     case 0: return lean_launch2<1, 4, 1, 4>(p, B, xfk, epi, st);
     case 1: return lean_launch2<2, 4, 1, 4>(p, B, xfk, epi, st);

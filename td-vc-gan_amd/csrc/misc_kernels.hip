@@ -29,7 +29,6 @@ namespace tdvc {
 int g_trace_on = 0;
 int g_force_tile = -1;
 int g_lds_cap = 0;
-int g_lean_db_mask = 0x36;      // bit cfg: tile configuration runs the pipelined main loop (conv_lean_db.hip); cfgs 1, 2, 4, 5
 static std::mutex g_trace_mu;
 static std::set<std::string> g_trace_names;
 void trace_kernel(const void* fn) {
@@ -49,7 +48,6 @@ void trace_kernel(const void* fn) {
 }  // namespace tdvc
 extern "C" void tdvc_debug_force_tile(int cfg) { tdvc::g_force_tile = cfg; }
 extern "C" void tdvc_debug_lds_cap(int bytes) { tdvc::g_lds_cap = bytes; }
-extern "C" void tdvc_debug_lean_db(int mask) { tdvc::g_lean_db_mask = mask; }
 extern "C" void tdvc_debug_trace(int on) {
   std::lock_guard<std::mutex> lk(tdvc::g_trace_mu);
   if (on == 1) tdvc::g_trace_names.clear();

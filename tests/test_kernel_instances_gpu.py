@@ -34,30 +34,20 @@ def _L():
     return importlib.import_module('td-vc-gan_amd')._lib
 
 
-DB_CFGS = (1, 2, 4, 5)      # tile configurations that have the software-pipelined main loop (conv_lean_db.hip), plain prologue
-
-
-def lean_name(cfg, xfk, epi, db=False):
+def lean_name(cfg, xfk, epi):
     m, n, wm, wn = LEAN_CFG[cfg]
-    if db and xfk == LXF_ACT and cfg in DB_CFGS:
-        return f'conv_lean_db_kernel<{m},{n},{wm},{wn},{epi}>'
     return f'conv_lean_kernel<{m},{n},{wm},{wn},{xfk},{epi}>'
 
 
-def _run_forced(cfg, fn, db=True):
+def _run_forced(cfg, fn):
     L = _L()
     L.lib().tdvc_debug_force_tile(cfg)
-    L.lib().tdvc_debug_lean_db(0x36 if db else 0)
     try:
         with traced() as tr:
             errs = fn()
     finally:
         L.lib().tdvc_debug_force_tile(-1)
-        L.lib().tdvc_debug_lean_db(0x36)
     return errs, tr.names
-
-
-MAIN_LOOPS = [pytest.param(True, id='pipelined'), pytest.param(False, id='single-stage')]
 
 
 # ------------------------------------------------------------------------------------------------ (a) forced tiles
@@ -69,16 +59,13 @@ FILM_SHAPES = [(16, 3, 1, 520, True, True), (16, 11, 5, 332, True, False), (32, 
 
 @pytest.mark.parametrize('shape', FILM_SHAPES, ids=[f'C{c}k{k}d{d}T{t}' + ('' if cond else '_nocond') for c, k, d, t, cond, _ in FILM_SHAPES])
 @pytest.mark.parametrize('cfg', sorted(LEAN_CFG), ids=[f'tile{c}_' + 'x'.join(map(str, LEAN_CFG[c])) for c in sorted(LEAN_CFG)])
-@pytest.mark.parametrize('db', MAIN_LOOPS)
-def test_forced_tile_film_block(cfg, shape, db, dev):
-    if not db and cfg not in DB_CFGS:
-        pytest.skip('this tile configuration has only the single-stage main loop')
-    errs, names = _run_forced(cfg, lambda: OPS.film_block_errors(shape, dev, B=2), db)
+def test_forced_tile_film_block(cfg, shape, dev):
+    errs, names = _run_forced(cfg, lambda: OPS.film_block_errors(shape, dev, B=2))
     assert max(errs.values()) < TOL, errs
-    want = [lean_name(cfg, LXF_ACT, EPI_FWD, db), lean_name(cfg, LXF_ACT, EPI_MASK, db)]
-    want += [lean_name(cfg, LXF_FILM, EPI_FWD), lean_name(cfg, LXF_ACT, EPI_FILM, db)] if shape[4] else []
+    want = [lean_name(cfg, LXF_ACT, EPI_FWD), lean_name(cfg, LXF_ACT, EPI_MASK)]
+    want += [lean_name(cfg, LXF_FILM, EPI_FWD), lean_name(cfg, LXF_ACT, EPI_FILM)] if shape[4] else []
     missing = [w for w in want if w not in names]
-    assert not missing, (missing, sorted(n for n in names if 'lean' in n))
+    assert not missing, (missing, sorted(n for n in names if 'lean_kernel' in n))
 
 
 # Plain conv cases (tests/test_conv_ops_gpu.py layout): (name, cin, cout, k, stride, pad, dil, groups, reflect, transposed, T, pre, post)
@@ -98,18 +85,15 @@ FORCED_CONV = [
 
 @pytest.mark.parametrize('case', FORCED_CONV, ids=[c[0] for c in FORCED_CONV])
 @pytest.mark.parametrize('cfg', sorted(LEAN_CFG), ids=[f'tile{c}_' + 'x'.join(map(str, LEAN_CFG[c])) for c in sorted(LEAN_CFG)])
-@pytest.mark.parametrize('db', MAIN_LOOPS)
-def test_forced_tile_conv(cfg, case, db, dev):
-    if not db and cfg not in DB_CFGS:
-        pytest.skip('this tile configuration has only the single-stage main loop')
+def test_forced_tile_conv(cfg, case, dev):
     T = case[10]
     if T <= 80 and LEAN_CFG[cfg][1] * LEAN_CFG[cfg][3] * 16 == 256:
         pytest.skip('256-column tiles are never selected for T <= 80 (launch_conv_lean)')
-    errs, names = _run_forced(cfg, lambda: OPS.conv_case_errors(case[:13], dev, 0, B=3), db)
+    errs, names = _run_forced(cfg, lambda: OPS.conv_case_errors(case[:13], dev, 0, B=3))
     assert max(errs.values()) < TOL, errs
-    want = [lean_name(cfg, LXF_ACT, EPI_FWD, db), lean_name(cfg, *case[13], db)]
+    want = [lean_name(cfg, LXF_ACT, EPI_FWD), lean_name(cfg, *case[13])]
     missing = [w for w in want if w not in names]
-    assert not missing, (missing, sorted(n for n in names if 'lean' in n))
+    assert not missing, (missing, sorted(n for n in names if 'lean_kernel' in n))
 
 
 # ------------------------------------------------------------------------------------------------ (b) launch shapes
@@ -127,7 +111,7 @@ def test_launch_shape_film_block(shape, B, dev):
     with traced() as tr:
         errs = OPS.film_block_errors(shape, dev, B=B)
     assert max(errs.values()) < TOL, (errs, sorted(tr.names))
-    assert any('conv_lean_kernel' in n or 'conv_lean_db_kernel' in n for n in tr.names), sorted(tr.names)
+    assert any('conv_lean_kernel' in n for n in tr.names), sorted(tr.names)
 
 
 # (name, cin, cout, k, stride, pad, dil, groups, reflect, transposed, T, pre, post), B

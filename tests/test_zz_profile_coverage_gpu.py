@@ -15,7 +15,7 @@ from common import SESSION_KERNELS, pkg
 
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-TRACED_FAMILIES = ('conv_lean_kernel', 'conv_lean_db_kernel', 'conv_wgrad_pipe_kernel', 'conv_wgrad_tile_kernel', 'conv_wgrad_lean_kernel', 'conv_gemm_kernel',
+TRACED_FAMILIES = ('conv_lean_kernel', 'conv_wgrad_pipe_kernel', 'conv_wgrad_tile_kernel', 'conv_wgrad_lean_kernel', 'conv_gemm_kernel',
                    'conv_wgrad_kernel', 'conv_scalar_kernel', 'conv_wgrad_scalar_kernel', 'film_cond0_bwd_kernel', 'film_block_kernel',
                    'wn_gate_kernel')
 

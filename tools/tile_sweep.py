@@ -61,12 +61,9 @@ def main():
         if True:
             calls, keep = cond_calls(C2, T) if which == 'cond' else conv_calls(cin, C2, T, which, k=k, BL=bl)
             res = []
-            for cap in ((0,) if os.environ.get('SWEEP_CAPS') is None else (0, 52 * 1024, 40 * 1024)):
-              for db in (0x36, 0):
+            for cap in (0, 52 * 1024, 40 * 1024):
                 for cfg in ((-1,) if which == 'cond' else (-1, 0, 1, 2, 4, 5, 6)):
-                    if db == 0 and cfg in (0, 6):
-                        continue
-                    lib.tdvc_debug_lds_cap(cap); lib.tdvc_debug_force_tile(cfg); lib.tdvc_debug_lean_db(db)
+                    lib.tdvc_debug_lds_cap(cap); lib.tdvc_debug_force_tile(cfg)
                     lib.tdvc_debug_trace(1)
                     try:
                         calls[0]()
@@ -78,7 +75,6 @@ def main():
                     lib.tdvc_debug_trace(0)
                     ms = bench.time_launches(torch, calls, 30)
                     res.append((cap, cfg, ms, name))
-            lib.tdvc_debug_lean_db(0x36)
             lib.tdvc_debug_lds_cap(0); lib.tdvc_debug_force_tile(-1)
             print(f'== {cin}->{C2} k{k} T={T} B={bl} {which}', flush=True)
             for cap, cfg, ms, name in res:
