@@ -576,6 +576,9 @@ hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st) {
     MT = c.MT; NT = c.NT; cfg = c.cfg;
     if (blocks >= 512) break;
   }
+  // a tiny reduction (the 8-channel excitation window of cond_var.0: Cin*K = 24) makes the conv a pure HBM stream of its
+  // output: the 16-row tile keeps the most blocks resident (94 vs 111 us for 8 -> 136, T = 16000, 32 samples)
+  if ((long)p.Cin * p.K <= 48 && p.T > 80 && p.mirror == 0) { MT = 16; NT = 256; cfg = 0; }
   if (g_force_tile >= 0) {   // test-only (tdvc_debug_force_tile): pin the tile so that small shapes reach every instance
     for (const Cand& c : cands)
       if (c.cfg == g_force_tile) { MT = c.MT; NT = c.NT; cfg = c.cfg; }
@@ -589,9 +592,9 @@ hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st) {
   p.XS = ((p.span + 31) / 32) * 32 + 16;
   const int xvp = MT >= 32 ? 12 : 6, wvp = MT >= 48 ? 10 : (MT >= 32 ? 6 : 4);   // = the kernel's XVP / WVP
   // LDS budget per block = what lets the blocks the register budget allows (launch_bounds of the instance) actually be
-  // resident on a CU with 160 KB: 3 blocks for the 32-row x 256-column tile -> 52 KB (with 64 KB only two fit and the
-  // kernel ran 22 % slower: tools/tile_sweep.py), 64 KB for the 2-blocks-per-CU tiles and the narrow ones.
-  const size_t lds_cap = g_lds_cap > 0 ? (size_t)g_lds_cap : (size_t)((MT == 32 && NT == 256) ? 52 : 64) * 1024;
+  // resident on a CU with 160 KB: 3 blocks -> 52 KB. With 64 KB only two 32-row x 256-column blocks fit and that kernel
+  // ran 22 % slower; the other tiles gain 0-6 % (tools/tile_sweep.py, profiles/r02_b_tile_sweep.txt).
+  const size_t lds_cap = g_lds_cap > 0 ? (size_t)g_lds_cap : (size_t)52 * 1024;
   int Cc = 0;
   for (int cc = 4; cc <= 32 && cc <= ((p.Cin + 3) / 4) * 4; cc += 4) {
     int xrp, xnp, wrp, wnp;
