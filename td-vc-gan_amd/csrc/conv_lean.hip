@@ -579,6 +579,10 @@ hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st) {
   // a tiny reduction (the 8-channel excitation window of cond_var.0: Cin*K = 24) makes the conv a pure HBM stream of its
   // output: the 16-row tile keeps the most blocks resident (94 vs 111 us for 8 -> 136, T = 16000, 32 samples)
   if ((long)p.Cin * p.K <= 48 && p.T > 80 && p.mirror == 0) { MT = 16; NT = 256; cfg = 0; }
+  // short reductions with many (R = 136: the input-grad of cond_var.2 at the 16/32-channel stages) or few (R = 32)
+  // output rows are bound by their epilogue traffic, not by the matrix pipe: 16-row tiles (5 blocks per CU) measured
+  // 4-10 % faster than the 48/32-row ones there (profiles/r02_b_tile_sweep.txt)
+  if ((long)p.Cin * p.K <= 224 && p.T > 80 && (R >= 128 || R == 32)) { MT = 16; NT = 256; cfg = 0; }
   if (g_force_tile >= 0) {   // test-only (tdvc_debug_force_tile): pin the tile so that small shapes reach every instance
     for (const Cand& c : cands)
       if (c.cfg == g_force_tile) { MT = c.MT; NT = c.NT; cfg = c.cfg; }
