@@ -115,7 +115,7 @@ def kernel_table(pkg, dev, B, step_ms, iters=40, manifest=None):
         e['frac'] = e['achieved'] / e['peak']
         rows.append(e)
 
-    def conv_case(label, n, bound, cin, cout, k, dil, T, reflect, pre, which, Bc, post=0, film=False):
+    def conv_case(label, n, bound, cin, cout, k, dil, T, reflect, pre, which, Bc, post=0, film=False, bias3=False):
         pad = (k - 1) * dil // 2
         spec = ops.ConvSpec(cin, cout, k, 1, pad, dil, 1, reflect)
         w = torch.randn(cout, cin, k, device=dev) / (cin * k) ** 0.5
@@ -123,7 +123,8 @@ def kernel_table(pkg, dev, B, step_ms, iters=40, manifest=None):
         dw, db = torch.zeros_like(w), torch.zeros_like(b)
         wt = w.permute(1, 0, 2).contiguous()
         spec.slot = arena.ConvSlot(w.data_ptr(), b.data_ptr(), dw.data_ptr(), db.data_ptr(), True, None, wt.data_ptr())
-        keep.extend([w, b, dw, db, wt])
+        k3b = torch.randn(Bc, cout, 3, device=dev) * 0.1 if bias3 else None
+        keep.extend([w, b, dw, db, wt, k3b])
         # operands of the launch exactly as the step passes them (distinct tensors for input / mask source / output)
         if which == 'fwd':
             shapes = dict(x=(Bc, cin, T), y=(Bc, cout, T))
@@ -149,13 +150,19 @@ def kernel_table(pkg, dev, B, step_ms, iters=40, manifest=None):
             dyxf = (lambda s=s: ops._xf(L.XF_MASK_LRELU, aux=s['act'])) if post else (lambda s=s: ops._xf())
             if which == 'fwd':
                 xf = ops._xf(L.XF_FILM_LRELU, aux=s['gb']) if film else ops._xf(L.XF_LRELU if pre else L.XF_NONE)
-                calls.append(lambda s=s, xf=xf: ops.conv_fwd_raw(spec, s['x'], xf, post=post, res=s.get('res'), out=s['y']))
+                calls.append(lambda s=s, xf=xf: ops.conv_fwd_raw(spec, s['x'], xf, post=post, res=s.get('res'), out=s['y'], bias3=k3b))
             elif which == 'dgrad':
                 calls.append(lambda s=s, f=dyxf: ops.conv_dgrad_raw(spec, s['dy'], f(), T, L.DG_MASK_LRELU if pre else L.DG_PLAIN,
                                                                     x_in=s.get('x_in'), out=s['dx']))
             else:
                 xf = ops._xf(L.XF_LRELU if pre else L.XF_NONE)
-                calls.append(lambda s=s, xf=xf, f=dyxf: ops.conv_wgrad_raw(spec, s['x'], xf, s['dy'], f()))
+                parts = ops._wgrad_cin_split(spec)          # 136 input channels run as 128 + 8, exactly as the step does
+                if parts is None:
+                    calls.append(lambda s=s, xf=xf, f=dyxf: ops.conv_wgrad_raw(spec, s['x'], xf, s['dy'], f()))
+                else:
+                    sa, sb, nm = parts
+                    calls.append(lambda s=s, xf=xf, f=dyxf: (ops.conv_wgrad_raw(sa, s['x'][:, :nm], xf, s['dy'], f()),
+                                                             ops.conv_wgrad_raw(sb, s['x'][:, nm:], xf, s['dy'], f())))
         alg = 4.0 * Bc * T * words + 4.0 * (w.numel() + cout)
         add(label, n, bound, alg, 2.0 * Bc * T * cin * cout * k, calls, bufs.bytes_per_rotation)
 
@@ -201,7 +208,12 @@ def kernel_table(pkg, dev, B, step_ms, iters=40, manifest=None):
     for C2, T in stages:
         tag = f'136->{C2} k3 T={T} B={BL}'
         conv_case(f'FiLM cond_var.2 input-grad {tag}', 9, 'mfma', 136, C2, 3, 1, T, False, 1, 'dgrad', BL)
-        cond_fwd_case(f'FiLM conditioning fwd (cond_var.0 fused into cond_var.2) {tag}', 9, C2, T, BL)
+        if ops.FUSED_COND_FWD:
+            cond_fwd_case(f'FiLM conditioning fwd (cond_var.0 fused into cond_var.2) {tag}', 9, C2, T, BL)
+        else:       # the step's default: two launches
+            conv_case(f'FiLM cond_var.0 excitation window 8->136 k3 T={T} B={BL} fwd (+ 3-valued embedding bias)', 9, 'hbm', 8, 136, 3, 1, T, False, 0,
+                      'fwd', BL, bias3=True)
+            conv_case(f'FiLM cond_var.2 fwd {tag} (LeakyReLU on load)', 9, 'mfma', 136, C2, 3, 1, T, False, 1, 'fwd', BL)
         conv_case(f'FiLM cond_var.2 weight-grad {tag}', 9, 'mfma', 136, C2, 3, 1, T, False, 1, 'wgrad', BL)
         cond0_bwd_case(f'FiLM cond_var.0 backward (dexc + dW window + dk3) 136ch T={T} B={BL}', 9, T, BL)
         keep.clear()
