@@ -393,7 +393,7 @@ def main():
                    config=dict(workload=f'config/{args.config}.yaml full D+G iteration, {B} x 1 s @16 kHz per GPU, NUM_SPK=16, '
                                         'F0 (CREPE) loss term excluded', global_batch=world * B, parallelism=f'dp{world}'),
                    final_G_loss=g_loss, launch=launch)
-        if not args.no_kernel_table and 'stage1' in args.config:
+        if world == 1 and not args.no_kernel_table and 'stage1' in args.config:      # rank 0 of a multi-rank run goes straight to the JSON line
             table, north = kernel_table(pkg, dev, B, step_ms)
             dom = table[0]
             roof = {k: dom[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'kernel', 'op', 'ms_per_launch', 'launches_per_step',
