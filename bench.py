@@ -156,13 +156,7 @@ def kernel_table(pkg, dev, B, step_ms, iters=40, manifest=None):
                                                                     x_in=s.get('x_in'), out=s['dx']))
             else:
                 xf = ops._xf(L.XF_LRELU if pre else L.XF_NONE)
-                parts = ops._wgrad_cin_split(spec)          # 136 input channels run as 128 + 8, exactly as the step does
-                if parts is None:
-                    calls.append(lambda s=s, xf=xf, f=dyxf: ops.conv_wgrad_raw(spec, s['x'], xf, s['dy'], f()))
-                else:
-                    sa, sb, nm = parts
-                    calls.append(lambda s=s, xf=xf, f=dyxf: (ops.conv_wgrad_raw(sa, s['x'][:, :nm], xf, s['dy'], f()),
-                                                             ops.conv_wgrad_raw(sb, s['x'][:, nm:], xf, s['dy'], f())))
+                calls.append(lambda s=s, xf=xf, f=dyxf: ops.conv_wgrad_raw(spec, s['x'], xf, s['dy'], f()))
         alg = 4.0 * Bc * T * words + 4.0 * (w.numel() + cout)
         add(label, n, bound, alg, 2.0 * Bc * T * cin * cout * k, calls, bufs.bytes_per_rotation)
 

@@ -255,6 +255,40 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 3 : 4)) void conv_gemm_
 
   // ---- epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + reg
   const int Cy_tot = p.groups * p.Cy_g;
+  if (MODE == MODE_UP && (p.s == 4 || p.s == 8) && (p.epi == EPI_PLAIN || p.epi == EPI_MASK) && !p.add && (p.pad & 3) == 0 && (p.Ty & 3) == 0 &&
+      (p.y_bs & 3) == 0 && (((uintptr_t)p.y) & 15) == 0 && (p.epi == EPI_PLAIN || ((p.mx_bs & 3) == 0 && (((uintptr_t)p.mx) & 15) == 0))) {
+    // Depth-to-time with stride 4 / 8: the lane's four accumulator rows are four CONSECUTIVE phases of one output channel,
+    // i.e. four consecutive output samples u0 .. u0+3 with u0 % 4 == 0 -> one dwordx4 store per 16x16 tile and lane
+    // (consecutive lanes = consecutive columns = consecutive float4) instead of four stride-s scalar stores.
+#pragma unroll
+    for (int m = 0; m < M_REP; ++m) {
+      const int row0 = r0 + wrow0_l + m * 16 + kq * 4;
+      if (row0 >= p.R) continue;
+      const int mm = row0 / p.s, phi0 = row0 - mm * p.s;
+      const long rbase = (long)(g * p.Cy_g + mm) * p.Ty;
+#pragma unroll
+      for (int n = 0; n < N_REP; ++n) {
+        const int col = n0 + wcol0 + n * 16 + ln;
+        if (col >= p.N) continue;
+        const int u0 = col * p.s + phi0 - p.pad;
+        if (u0 + 3 < 0 || u0 >= p.Ty) continue;
+        f32x4 v = acc[m][n];
+        if (u0 >= 0 && u0 + 3 < p.Ty) {
+          if (p.epi == EPI_MASK) {
+            const f32x4 mm4 = *reinterpret_cast<const f32x4*>(p.mx + (long)b * p.mx_bs + rbase + u0);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = mm4[q] > 0.f ? v[q] : v[q] * p.m_slope;
+          }
+          *reinterpret_cast<f32x4*>(p.y + (long)b * p.y_bs + rbase + u0) = v;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (u0 + q >= 0 && u0 + q < p.Ty) conv_epilogue(p, v[q], b, g * p.Cy_g + mm, u0 + q, Cy_tot);
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int m = 0; m < M_REP; ++m) {
 #pragma unroll

@@ -234,31 +234,6 @@ class FilmBlockFn(Function):
         return dx, dgb, (d_out if ctx.has_acc else None), None, None, None, None
 
 
-_WG_SPLIT = {}
-
-
-def _wgrad_cin_split(spec):
-    """Input-channel split of a stride-1 conv's weight-gradient: the pipelined kernel tiles the input channels by 64, so
-    a 136-channel operand costs three tiles (192 channels of MFMA work, 29 % of it padding). The first 128 channels go
-    through it as two full tiles and the remaining 8 through the narrow-layer kernel; both accumulate into their
-    input-channel window of the same weight gradient (tdvc_conv_desc.w_cin / w_cin_off). Returns (spec_main, spec_tail,
-    n_main) or None when the layer does not have that shape."""
-    key = (id(spec), id(spec.slot))
-    if key not in _WG_SPLIT:
-        main = spec.cin // 64 * 64
-        parts = None
-        if (spec.kind == L.CONV and spec.stride == 1 and spec.groups == 1 and spec.w_cin == 0 and main >= 64 and 0 < spec.cin - main <= 16
-                and spec.cout >= 32):
-            mk = lambda cin, off: ConvSpec(cin, spec.cout, spec.k, 1, spec.pad, spec.dil, 1, bool(spec.reflect), w_cin=spec.cin, w_cin_off=off)
-            a, b = mk(main, 0), mk(spec.cin - main, main)
-            sl = spec.slot
-            a.slot = sl
-            b.slot = ConvSlot(sl.w, 0, sl.dw, 0, sl.trainable, sl.arena, sl.wt, sl.seg)       # the bias gradient is taken once (part a)
-            parts = (a, b, main)
-        _WG_SPLIT[key] = parts
-    return _WG_SPLIT[key]
-
-
 FUSED_COND_FWD = os.environ.get('TDVC_FUSED_COND_FWD', '0') == '1'     # single-launch conditioning forward (tdvc_film_cond_fwd)
 
 
@@ -294,13 +269,7 @@ class FilmCondFn(Function):
         exc, cv0 = ctx.saved_tensors
         dgb = dgb.contiguous()
         B, nc, T = cv0.shape
-        parts = _wgrad_cin_split(ctx.s2)
-        if parts is None:
-            conv_wgrad_raw(ctx.s2, cv0, _xf(L.XF_LRELU), dgb, _xf())
-        else:       # 136 input channels = 128 (two full 64-channel tiles of the pipelined kernel) + 8 (narrow kernel)
-            sa, sb, main = parts
-            conv_wgrad_raw(sa, cv0[:, :main], _xf(L.XF_LRELU), dgb, _xf())
-            conv_wgrad_raw(sb, cv0[:, main:], _xf(L.XF_LRELU), dgb, _xf())
+        conv_wgrad_raw(ctx.s2, cv0, _xf(L.XF_LRELU), dgb, _xf())
         dcv = conv_dgrad_raw(ctx.s2, dgb, _xf(), T, L.DG_MASK_LRELU, x_in=cv0)
         # everything that consumes d_cv0 in one pass over it: dexc, the excitation window of cond_var.0's weight-grad, dk3
         lib = L.lib()
