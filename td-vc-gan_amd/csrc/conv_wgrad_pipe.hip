@@ -64,12 +64,6 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const WgLeanP p
   for (int i = 0; i < AP; ++i) bias_acc[i] = 0.f;
   const bool want_bias = p.bias_off >= 0 && ct == 0;
 
-  // wave-uniform: which of the wave's 16-channel column sub-tiles hold real input channels (the last channel tile of a
-  // 136-channel operand has 8 of 64: three quarters of its MFMA work would multiply zeros)
-  bool cok[C_REP];
-#pragma unroll
-  for (int c = 0; c < C_REP; ++c) cok[c] = __builtin_amdgcn_readfirstlane((c0 + (wc * C_REP + c) * 16 < p.Cin) ? 1 : 0) != 0;
-
   const int nchunks = p.ntiles * p.B;
   const int q_begin = blockIdx.x * p.tpb, q_end = min(nchunks, q_begin + p.tpb);
   if (q_begin >= q_end) return;                // uniform per block
@@ -205,22 +199,18 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_pipe_kernel(const WgLeanP p
 #pragma unroll
       for (int m = 0; m < M_REP; ++m) av[buf][m] = a_lane[nn + m * 16 * WP_AS];
 #pragma unroll
-      for (int c = 0; c < C_REP; ++c) {
-        if (!cok[c]) continue;
+      for (int c = 0; c < C_REP; ++c)
 #pragma unroll
         for (int j = 0; j < J; ++j) bv[buf][c][j] = x_lane[nn + c * 16 * XSW + j * D];
-      }
     };
     auto mma = [&](int buf) {
 #pragma unroll
       for (int m = 0; m < M_REP; ++m)
 #pragma unroll
-        for (int c = 0; c < C_REP; ++c) {
-          if (!cok[c]) continue;                 // 16-channel sub-tile past Cin (136 = 2 x 64 + 8): nothing to accumulate
+        for (int c = 0; c < C_REP; ++c)
 #pragma unroll
           for (int j = 0; j < J; ++j)
             acc[m][c][j] = __builtin_amdgcn_mfma_f32_16x16x4f32(av[buf][m], bv[buf][c][j], acc[m][c][j], 0, 0, 0);
-        }
     };
     load_frag(0, 0);
 #pragma unroll
