@@ -20,6 +20,9 @@ struct WgLeanP {
 hipError_t launch_conv_wgrad_lean(WgLeanP p, int B, int J, int D, hipStream_t st);
 bool wgrad_lean_supported(int J, int D);
 int wgrad_lean_nslab(int R, int Cin, int N, int K, int B);
+// 136 input channels cost 3 tiles of 64 (192, 29 % padding) but 5 tiles of 32 (160, 15 %): take the narrower tile when it
+// saves more than 10 % of the MFMA work
+static inline bool wgrad_prefers_ct32(int Cin) { return ((Cin + 31) / 32 * 32) * 10 < ((Cin + 63) / 64 * 64) * 9; }
 // pipelined register-tile kernel (conv_wgrad_pipe.hip); returns hipErrorNotSupported outside its contract
 hipError_t launch_conv_wgrad_pipe(WgLeanP& p, int J, int D, hipStream_t st);
 

@@ -365,10 +365,10 @@ static hipError_t wg_launch_jd(WgLeanP& p, int B, hipStream_t st) {
   // wide layers: 64-step chunks, register tile per wave
   p.span = ((WT_NTC + (J - 1) * D - p.pad - p.lo) + 3) / 4 * 4;
   if (p.R <= 32) {
-    if (J <= 3) return wt_launch<1, 2, J, D>(p, B, st);    // 32 x 64 block tile, 16 x 32 per wave
+    if (J <= 3 && !wgrad_prefers_ct32(p.Cin)) return wt_launch<1, 2, J, D>(p, B, st);    // 32 x 64 block tile, 16 x 32 per wave
     return wt_launch<1, 1, J, D>(p, B, st);                 // 32 x 32 block tile
   }
-  if (J <= 3) return wt_launch<2, 2, J, D>(p, B, st);      // 64 x 64 block tile, 32 x 32 per wave
+  if (J <= 3 && !wgrad_prefers_ct32(p.Cin)) return wt_launch<2, 2, J, D>(p, B, st);      // 64 x 64 block tile, 32 x 32 per wave
   return wt_launch<2, 1, J, D>(p, B, st);                   // 64 x 32 block tile, 32 x 16 per wave
 }
 
@@ -376,7 +376,7 @@ static hipError_t wg_launch_jd(WgLeanP& p, int B, hipStream_t st) {
 void wgrad_lean_plan(int R, int Cin, int N, int K, int B, int* ntiles, int* tpb, int* ngroups) {
   const bool narrow = (R <= 16 || Cin <= 16);
   const int ntc = narrow ? WG_NTC : WT_NTC;
-  const int mt = narrow ? 16 : ((R <= 32 || K >= 11) ? 32 : 64), ctw = narrow ? 16 : (K <= 3 ? 64 : 32);
+  const int mt = narrow ? 16 : ((R <= 32 || K >= 11) ? 32 : 64), ctw = narrow ? 16 : ((K <= 3 && !wgrad_prefers_ct32(Cin)) ? 64 : 32);
   *ntiles = (N + ntc - 1) / ntc;
   const long tiles = (long)((R + mt - 1) / mt) * ((Cin + ctw - 1) / ctw);
   const long blocks = (long)B * (*ntiles) * tiles;

@@ -299,11 +299,12 @@ static hipError_t wp_launch(WgLeanP& p, hipStream_t st) {
 template <int J, int D>
 static hipError_t wp_launch_jd(WgLeanP& p, hipStream_t st) {
   p.span = ((WP_NTC + (J - 1) * D - p.pad - p.lo) + 3) / 4 * 4;
+  const bool ct64 = J <= 3 && !wgrad_prefers_ct32(p.Cin);   // 64 input channels per block tile unless that pads too much (136)
   if (p.R <= 32 || J >= 11) {                             // (11 taps: the 64-row tile would spill its accumulators)
-    if (J <= 3) return wp_launch<1, 2, J, D>(p, st);     // 32 x 64 block tile, 16 x 32 per wave
+    if (ct64) return wp_launch<1, 2, J, D>(p, st);       // 32 x 64 block tile, 16 x 32 per wave
     return wp_launch<1, 1, J, D>(p, st);                  // 32 x 32 block tile
   }
-  if (J <= 3) return wp_launch<2, 2, J, D>(p, st);       // 64 x 64 block tile, 32 x 32 per wave
+  if (ct64) return wp_launch<2, 2, J, D>(p, st);         // 64 x 64 block tile, 32 x 32 per wave
   return wp_launch<2, 1, J, D>(p, st);                    // 64 x 32 block tile, 32 x 16 per wave
 }
 
