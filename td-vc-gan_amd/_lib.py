@@ -80,6 +80,7 @@ SIGNATURES = {
     'tdvc_set_force_generic': (None, [_i]),
     'tdvc_debug_force_tile': (None, [_i]),
     'tdvc_debug_lds_cap': (None, [_i]),
+    'tdvc_debug_knob': (None, [_i, _i]),
     'tdvc_debug_trace': (None, [_i]),
     'tdvc_debug_trace_dump': (C.c_size_t, [C.c_char_p, C.c_size_t]),
     'tdvc_weight_norm_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),

@@ -25,6 +25,7 @@ namespace tdvc {
 extern int g_trace_on;
 extern int g_force_tile;
 extern int g_lds_cap;
+extern int g_knob[8];   // tuning knobs (tdvc_debug_knob): [0] XCD-aware block order of the lean conv kernel (default off: measured null, profiles/r02_e_xcd_remap_ab.txt)
 void trace_kernel(const void* fn);
 }
 #define TDVC_TRACE(k) do { if (tdvc::g_trace_on) tdvc::trace_kernel(reinterpret_cast<const void*>(k)); } while (0)

@@ -48,11 +48,17 @@ __device__ __forceinline__ float lean_fetch(const LeanP& p, int b, int c, int q)
 #ifndef LEAN_OCC_SMALL
 #define LEAN_OCC_SMALL 4      // resident blocks per CU asked for the 16-row tiles (A/B knob: make ab EXTRA=-DLEAN_OCC_SMALL=5)
 #endif
+// Resident blocks per CU the register budget must allow: 2 for the 48/64/144-row x 256/64-column tiles (>= 36 accumulator
+// registers), 3 for 32 x 256, 4 for the rest -- including the 64 x 64 tile (16 accumulator registers), whose 1024-block
+// grids (D layer 5) then run as ONE round instead of 1.33 rounds of 768 slots.
+constexpr int lean_min_blocks(int m_rep, int n_rep, int wm, int xfk) {
+  return m_rep * n_rep >= 9 ? 2 : ((m_rep * n_rep >= 8 || (wm == 4 && xfk == LXF_FILM)) ? 3 : LEAN_OCC_SMALL);   // (FiLM prologue on 64 x 64: 12 spills at 4)
+}
 template <int M_REP, int N_REP, int WM, int WN, int XFK, int EPI>
-__global__ __launch_bounds__(256, (M_REP * N_REP >= 12 ? 2 : ((M_REP * N_REP >= 8 || 16 * M_REP * WM >= 48) ? 3 : LEAN_OCC_SMALL))) void conv_lean_kernel(const LeanP p) {
+__global__ __launch_bounds__(256, lean_min_blocks(M_REP, N_REP, WM, XFK)) void conv_lean_kernel(const LeanP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int MT = 16 * M_REP * WM, NT = 16 * N_REP * WN;
-  constexpr int XVP = MT >= 32 ? 12 : 6;                  // max row-walk passes of the prefetched input tile
+  constexpr int XVP = (M_REP >= 9 || NT <= 64) ? 4 : (MT >= 32 ? 12 : 6);   // max row-walk passes of the prefetched input tile
   constexpr int WVP = MT >= 48 ? 10 : (MT >= 32 ? 6 : 4);   // ... and of the weight tile
   float* xs = smem;
   float* ws = smem + p.xnp * p.xrp * p.XS;
@@ -63,7 +69,22 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 12 ? 2 : ((M_REP * N_REP >= 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
   const int ln = lane & 15, kq = lane >> 4;
-  const int n0 = blockIdx.x * NT, r0 = blockIdx.y * MT, b = blockIdx.z;
+  // Block order. The dispatcher deals blocks round-robin over the 8 XCDs (private L2 each), so with the plain
+  // (time tile, row tile, sample) order the row tiles that read one input tile, and the time neighbours that share
+  // its halo, sit behind eight different L2s. Remap (bijective for any grid size, cdna_hip_programming.md T1): the
+  // blocks that share an XCD take one contiguous run of work items, row tile fastest, then time, then sample.
+  int bx = blockIdx.x, by = blockIdx.y, bz = blockIdx.z;
+  if (p.swz) {
+    const int gx = gridDim.x, gy = gridDim.y;
+    const int nwg = gx * gy * gridDim.z;
+    const int orig = bx + gx * (by + gy * bz);
+    const int q = nwg >> 3, r = nwg & 7, xcd = orig & 7;
+    const int wg = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (orig >> 3);
+    by = wg % gy;
+    const int t = wg / gy;
+    bx = t % gx; bz = t / gx;
+  }
+  const int n0 = bx * NT, r0 = by * MT, b = bz;
   const int wcol0 = wn * 16 * N_REP, wrow0 = wm * 16 * M_REP;
   PROF_DECL
 
@@ -191,7 +212,7 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 12 ? 2 : ((M_REP * N_REP >= 
             *reinterpret_cast<f32x4*>(xs + cl * p.XS + t0) = act;
             // the block row 0 of each time tile also materialises cv0 (own columns only) for the backward pass
             const int pos0 = q0 + t0;
-            if (p.cv0 && blockIdx.y == 0 && cl < cvalid && pos0 >= n0 && pos0 < n0 + NT && pos0 < p.T)
+            if (p.cv0 && by == 0 && cl < cvalid && pos0 >= n0 && pos0 < n0 + NT && pos0 < p.T)
               *reinterpret_cast<f32x4*>(p.cv0 + (long)b * p.cv0_bs + (long)(c0 + cl) * p.T + pos0) = raw;
           }
         }
@@ -506,8 +527,9 @@ static hipError_t lean_launch3(const LeanP& p, int B, hipStream_t st) {
   auto k = conv_lean_kernel<M_REP, N_REP, WM, WN, XFK, EPI>;
   TDVC_BIG_LDS_ONCE(k); TDVC_TRACE(k);
   dim3 grid((p.T + NT - 1) / NT, (p.Cout + MT - 1) / MT, B);
+  LeanP q = p; q.swz = g_knob[0] && (long)grid.x * grid.y * grid.z >= 16;
   const size_t lds = (size_t)(p.xnp * p.xrp * p.XS + p.wnp * p.wrp * p.WS) * sizeof(float);
-  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, q);
   return hipGetLastError();
 }
 
@@ -533,7 +555,7 @@ hipError_t launch_conv_lean_cond(LeanP p, int B, hipStream_t st) {
   const int lo = -4;                                   // aligned origin
   p.lo = lo; p.i0 = first - lo;
   p.span = ((NT + (p.K - 1) * p.d - p.pad - lo) + 3) / 4 * 4;
-  p.XS = ((p.span + 31) / 32) * 32 + 16;
+  p.XS = ((p.span + 15) / 32) * 32 + 16;           // smallest stride >= span that is 16 (mod 32): the 4 rows of a fragment read hit disjoint banks
   p.ES = ((p.span + 15) / 16) * 16 + 4;
   int Cc = 32;
   auto geom = [&](int cc) {
@@ -545,6 +567,7 @@ hipError_t launch_conv_lean_cond(LeanP p, int B, hipStream_t st) {
   size_t lds = geom(Cc);
   if (lds > (size_t)(g_lds_cap > 0 ? g_lds_cap : 80 * 1024) || p.wnp > (MT >= 48 ? 10 : 6)) lds = geom(Cc = 16);
   dim3 grid((p.T + NT - 1) / NT, (p.Cout + MT - 1) / MT, B);
+  p.swz = g_knob[0] && (long)grid.x * grid.y * grid.z >= 16;
   if (MT == 32) {
     auto k = conv_lean_kernel<2, 4, 1, 4, LXF_COND, EPI_FWD>;
     TDVC_BIG_LDS_ONCE(k); TDVC_TRACE(k);
@@ -564,6 +587,7 @@ hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st) {
   // Tile choice: the largest tile whose grid still covers the chip ~2x (256 CUs), else the smallest one.
   struct Cand { int MT, NT, cfg; };
   static const Cand cands[] = {{64, 256, 2}, {48, 256, 5}, {32, 256, 1}, {64, 64, 4}, {32, 64, 6}, {16, 256, 0}, {16, 64, 3}};
+  static const Cand tall = {144, 64, 7};     // all 136 rows of cond_var.2's input-grad / cond_var.0 in one block: the input tile is read once
   const int R = p.Cout;
   int MT = 16, NT = 64, cfg = 3;
   for (const Cand& c : cands) {
@@ -574,7 +598,9 @@ hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st) {
     if (c.NT == 256 && p.T <= 80) continue;
     const long blocks = (long)((R + c.MT - 1) / c.MT) * ((p.T + c.NT - 1) / c.NT) * B;
     MT = c.MT; NT = c.NT; cfg = c.cfg;
-    if (blocks >= 512) break;
+    // 64 x 64 blocks sit 4 to a CU: below one full round of them (D layer 5: exactly 1024) the 32 x 64 tile, with twice
+    // the blocks, fills the chip better (128 -> 128 k7 T = 500: 47.7 vs 51.0 us; 136 -> 256 input-grad: 55 vs 61)
+    if (blocks >= (c.cfg == 4 ? 1024 : 512)) break;
   }
   // a tiny reduction (the 8-channel excitation window of cond_var.0: Cin*K = 24) makes the conv a pure HBM stream of its
   // output: the 16-row tile keeps the most blocks resident (94 vs 111 us for 8 -> 136, T = 16000, 32 samples)
@@ -586,6 +612,7 @@ hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st) {
   if (g_force_tile >= 0) {   // test-only (tdvc_debug_force_tile): pin the tile so that small shapes reach every instance
     for (const Cand& c : cands)
       if (c.cfg == g_force_tile) { MT = c.MT; NT = c.NT; cfg = c.cfg; }
+    if (g_force_tile == tall.cfg) { MT = tall.MT; NT = tall.NT; cfg = tall.cfg; }
   }
   const int first = -p.pad;
   int lo = -p.pad - p.mirror;
@@ -593,12 +620,12 @@ hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st) {
   const int hi = (p.K - 1) * p.d - p.pad + p.mirror;
   p.lo = lo; p.i0 = first - lo;
   p.span = ((NT + hi - lo) + 3) / 4 * 4;
-  p.XS = ((p.span + 31) / 32) * 32 + 16;
-  const int xvp = MT >= 32 ? 12 : 6, wvp = MT >= 48 ? 10 : (MT >= 32 ? 6 : 4);   // = the kernel's XVP / WVP
+  p.XS = ((p.span + 15) / 32) * 32 + 16;           // smallest stride >= span that is 16 (mod 32): the 4 rows of a fragment read hit disjoint banks
+  const int xvp = (MT >= 144 || NT <= 64) ? 4 : (MT >= 32 ? 12 : 6), wvp = MT >= 48 ? 10 : (MT >= 32 ? 6 : 4);   // = the kernel's XVP / WVP
   // LDS budget per block = what lets the blocks the register budget allows (launch_bounds of the instance) actually be
   // resident on a CU with 160 KB: 3 blocks -> 52 KB. With 64 KB only two 32-row x 256-column blocks fit and that kernel
   // ran 22 % slower; the other tiles gain 0-6 % (tools/tile_sweep.py, profiles/r02_b_tile_sweep.txt).
-  const size_t lds_cap = g_lds_cap > 0 ? (size_t)g_lds_cap : (size_t)52 * 1024;
+  const size_t lds_cap = g_lds_cap > 0 ? (size_t)g_lds_cap : (size_t)((cfg == 4 ? 40 : 52) * 1024);   // 4 resident 64 x 64 blocks
   int Cc = 0;
   for (int cc = 4; cc <= 32 && cc <= ((p.Cin + 3) / 4) * 4; cc += 4) {
     int xrp, xnp, wrp, wnp;
@@ -618,6 +645,7 @@ hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st) {
     case 3: return lean_launch2<1, 1, 1, 4>(p, B, xfk, epi, st);
     case 5: return lean_launch2<3, 4, 1, 4>(p, B, xfk, epi, st);
     case 6: return lean_launch2<1, 2, 2, 2>(p, B, xfk, epi, st);
+    case 7: return lean_launch2<9, 1, 1, 4>(p, B, xfk, epi, st);
     default: return lean_launch2<1, 4, 4, 1>(p, B, xfk, epi, st);
   }
 }

@@ -29,6 +29,7 @@ namespace tdvc {
 int g_trace_on = 0;
 int g_force_tile = -1;
 int g_lds_cap = 0;
+int g_knob[8] = {0, 0, 0, 0, 0, 0, 0, 0};
 static std::mutex g_trace_mu;
 static std::set<std::string> g_trace_names;
 void trace_kernel(const void* fn) {
@@ -48,6 +49,7 @@ void trace_kernel(const void* fn) {
 }  // namespace tdvc
 extern "C" void tdvc_debug_force_tile(int cfg) { tdvc::g_force_tile = cfg; }
 extern "C" void tdvc_debug_lds_cap(int bytes) { tdvc::g_lds_cap = bytes; }
+extern "C" void tdvc_debug_knob(int which, int value) { if (which >= 0 && which < 8) tdvc::g_knob[which] = value; }
 extern "C" void tdvc_debug_trace(int on) {
   std::lock_guard<std::mutex> lk(tdvc::g_trace_mu);
   if (on == 1) tdvc::g_trace_names.clear();

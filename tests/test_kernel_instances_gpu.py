@@ -25,7 +25,7 @@ from common import traced
 pytestmark = pytest.mark.gpu
 TOL = 2e-5
 
-LEAN_CFG = {0: (1, 4, 1, 4), 1: (2, 4, 1, 4), 2: (4, 4, 1, 4), 3: (1, 1, 1, 4), 4: (1, 4, 4, 1), 5: (3, 4, 1, 4), 6: (1, 2, 2, 2)}
+LEAN_CFG = {0: (1, 4, 1, 4), 1: (2, 4, 1, 4), 2: (4, 4, 1, 4), 3: (1, 1, 1, 4), 4: (1, 4, 4, 1), 5: (3, 4, 1, 4), 6: (1, 2, 2, 2), 7: (9, 1, 1, 4)}
 LXF_ACT, LXF_FILM, LXF_MASK_LRELU = 0, 1, 2
 EPI_FWD, EPI_MASK, EPI_FILM, EPI_PLAIN = 0, 1, 2, 3
 

@@ -57,12 +57,20 @@ def main():
                 (64, 64, 4000, 'fwd', 7, 32), (64, 64, 4000, 'dgrad', 7, 32), (128, 128, 500, 'fwd', 7, 32), (128, 128, 500, 'dgrad', 7, 32),
                 (32, 32, 8000, 'fwd', 7, 32), (32, 32, 8000, 'dgrad', 7, 32), (32, 32, 8000, 'fwd', 1, 32), (64, 64, 4000, 'fwd', 1, 32),
                 (8, 136, 16000, 'fwd', 3, 32), (8, 136, 4000, 'fwd', 3, 32), (256, 256, 50, 'fwd', 7, 32)]
+    caps, cfgs = (0, 52 * 1024, 40 * 1024), (-1, 0, 1, 2, 4, 5, 6, 7)
+    if len(sys.argv) > 1 and sys.argv[1] == 'tall':      # the 136-row problems: 16- / 48-row tiles vs the 144 x 64 one
+        jobs = [(136, C2, T, 'dgrad', 3, BL) for C2, T in stages] + [(8, 136, T, 'fwd', 3, BL) for _, T in stages]
+        caps, cfgs = (0,), (-1, 0, 5, 7)
+    if len(sys.argv) > 1 and sys.argv[1] == 'd5':        # D layer 5 and the short-sequence trunk convs on the 64 x 64 tile
+        jobs = [(1024, 1024, 63, 'fwd', 5, 64), (1024, 1024, 63, 'dgrad', 5, 64), (1024, 1024, 32, 'fwd', 5, 64), (1024, 1024, 32, 'dgrad', 5, 64),
+                (128, 128, 500, 'fwd', 7, 32), (128, 128, 500, 'dgrad', 7, 32), (256, 256, 50, 'fwd', 7, 32), (136, 256, 500, 'dgrad', 3, 32)]
+        caps, cfgs = (0, 52 * 1024), (-1, 4, 6)
     for cin, C2, T, which, k, bl in jobs:
         if True:
             calls, keep = cond_calls(C2, T) if which == 'cond' else conv_calls(cin, C2, T, which, k=k, BL=bl)
             res = []
-            for cap in (0, 52 * 1024, 40 * 1024):
-                for cfg in ((-1,) if which == 'cond' else (-1, 0, 1, 2, 4, 5, 6)):
+            for cap in caps:
+                for cfg in ((-1,) if which == 'cond' else cfgs):
                     lib.tdvc_debug_lds_cap(cap); lib.tdvc_debug_force_tile(cfg)
                     lib.tdvc_debug_trace(1)
                     try:
