@@ -57,6 +57,7 @@ struct GemmConvP {
   int stage_rows;               // DOWN with a large stride: stage with lanes along the reduced rows
   int chan_stage;               // DOWN, chunk = whole channels (Cc % s == 0): coalesced time-to-depth staging per channel
   int w_nat;                    // weight rows are contiguous over (c,k) and float4-alignable (host-checked)
+  int w_packed;                 // p.w is the reduced-layout copy [g][R][Cred4][J] made by weight_repack_kernel: rows copy as float4
   float* y; long y_bs; int Ty; int Cy_g;
   int epi;
   const float* bias;
@@ -117,10 +118,12 @@ __device__ __forceinline__ float fetch_opnd(const Opnd& o, int b, int ch, int q,
 typedef float f32x4_t __attribute__((ext_vector_type(4)));
 
 // True when rows [q0, q0+span) of operand `o` can be staged with aligned 16-byte loads and no padding logic.
-__device__ __forceinline__ bool rows_fast_ok(const Opnd& o, int q0, int span) {
-  return q0 >= 0 && q0 + span <= o.T && (o.T & 3) == 0 && (o.bs & 3) == 0 && ((q0 | span) & 3) == 0 &&
-         (((uintptr_t)o.p) & 15) == 0 &&
+__device__ __forceinline__ bool rows_align_ok(const Opnd& o, int q0, int span) {
+  return (o.T & 3) == 0 && (o.bs & 3) == 0 && ((q0 | span) & 3) == 0 && (((uintptr_t)o.p) & 15) == 0 &&
          (o.xf.kind == XF_NONE || o.xf.kind == XF_LRELU || ((((uintptr_t)o.xf.aux) & 15) == 0 && (o.xf.aux_bs & 3) == 0));
+}
+__device__ __forceinline__ bool rows_fast_ok(const Opnd& o, int q0, int span) {
+  return q0 >= 0 && q0 + span <= o.T && rows_align_ok(o, q0, span);
 }
 
 // Register-staged row tiles, split into ISSUE (all global loads of a batch in flight at once) and COMMIT
@@ -132,19 +135,8 @@ struct RegTile { f32x4_t v[NV]; };
 
 template <int NV>
 __device__ __forceinline__ void tile_issue(RegTile<NV>& t, const float* base, int rowstride, int nvalid, int nrows, int span,
-                                           int cvalid /* valid floats per row, multiple of 4 */, int ebase, int tid) {
-  const int nvec = span >> 2, total = nrows * nvec;
-  const float inv = 1.0f / (float)nvec;
-#pragma unroll
-  for (int i = 0; i < NV; ++i) {
-    const int e = ebase + tid + i * 256;
-    const int r = (int)(((float)e + 0.5f) * inv);
-    const int vv = e - r * nvec;
-    t.v[i] = (f32x4_t){0.f, 0.f, 0.f, 0.f};
-    if (e < total && r < nvalid && 4 * vv < cvalid) t.v[i] = *reinterpret_cast<const f32x4_t*>(base + (long)r * rowstride + 4 * vv);
-  }
-}
-
+                                           int cvalid /* valid floats per row, multiple of 4 */, int ebase, int tid,
+                                           int vlo = 0, int vhi = 1 << 30 /* valid float4 columns [vlo, vhi): zero padding at sequence ends */);
 // kind NONE / LRELU use only `t`; MASK_* use `a` (activation output); FILM uses a = gamma, c = beta.
 template <int NV>
 __device__ __forceinline__ void tile_commit(const RegTile<NV>& t, const RegTile<NV>* a, const RegTile<NV>* c, const Xf& xf,
@@ -207,6 +199,24 @@ __device__ __forceinline__ srd_t make_srd(const float* base, int bytes) {   // w
 }
 __device__ __forceinline__ f32x4_t buf_load4(srd_t rs, int voff) {
   return __builtin_bit_cast(f32x4_t, __builtin_amdgcn_raw_buffer_load_b128(rs, voff, 0, 0));
+}
+
+// Raw buffer loads with an out-of-range offset for the elements that must read as zero: nothing selects on the loaded
+// value, so no s_waitcnt lands between the issue and the code that runs under the loads (a `cond ? load : 0` form made
+// the compiler wait for every load right where it was issued).
+template <int NV>
+__device__ __forceinline__ void tile_issue(RegTile<NV>& t, const float* base, int rowstride, int nvalid, int nrows, int span,
+                                           int cvalid, int ebase, int tid, int vlo, int vhi) {
+  const int nvec = span >> 2, total = nrows * nvec;
+  const float inv = 1.0f / (float)nvec;
+  const srd_t rs = make_srd(base, nvalid > 0 ? ((nvalid - 1) * rowstride + cvalid) * 4 : 0);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int e = ebase + tid + i * 256;
+    const int r = (int)(((float)e + 0.5f) * inv);
+    const int vv = e - r * nvec;
+    t.v[i] = buf_load4(rs, (e < total && r < nvalid && 4 * vv < cvalid && vv >= vlo && vv < vhi) ? (r * rowstride + 4 * vv) * 4 : 0x7f000000);
+  }
 }
 
 struct RowWalk { int voff, loff, gstep, lstep, nk; bool active; };   // nk: valid components of the thread's float4 (rows with T % 4 != 0)
@@ -281,15 +291,15 @@ __device__ __forceinline__ void walk_commit_w(const RegTile<NP>& t, const RowWal
 // Whole tile, not pipelined: batches of NV float4 per thread (x up to 3 source tensors) in flight at a time.
 template <int NV>
 __device__ __forceinline__ void stage_rows_batched(const Opnd& o, float* dst, int XS, int b, int ch0, int nvalid, int nrows,
-                                                   int q0, int span, int Ctot, int tid) {
+                                                   int q0, int span, int Ctot, int tid, int vlo = 0, int vhi = 1 << 30) {
   const int total = nrows * (span >> 2);
   const float* base = o.p + (long)b * o.bs + (long)ch0 * o.T + q0;
   const float* abase = o.xf.aux ? o.xf.aux + (long)b * o.xf.aux_bs + (long)ch0 * o.T + q0 : nullptr;
   for (int eb = 0; eb < total; eb += NV * 256) {
     RegTile<NV> t, a, c;
-    tile_issue<NV>(t, base, o.T, nvalid, nrows, span, span, eb, tid);
-    if (o.xf.kind >= XF_FILM_LRELU) tile_issue<NV>(a, abase, o.T, nvalid, nrows, span, span, eb, tid);
-    if (o.xf.kind == XF_FILM_LRELU) tile_issue<NV>(c, abase + (long)Ctot * o.T, o.T, nvalid, nrows, span, span, eb, tid);
+    tile_issue<NV>(t, base, o.T, nvalid, nrows, span, span, eb, tid, vlo, vhi);
+    if (o.xf.kind >= XF_FILM_LRELU) tile_issue<NV>(a, abase, o.T, nvalid, nrows, span, span, eb, tid, vlo, vhi);
+    if (o.xf.kind == XF_FILM_LRELU) tile_issue<NV>(c, abase + (long)Ctot * o.T, o.T, nvalid, nrows, span, span, eb, tid, vlo, vhi);
     tile_commit<NV>(t, &a, &c, o.xf, dst, XS, nvalid, nrows, span, eb, tid);
   }
 }

@@ -4,6 +4,7 @@
 // epilogue (bias, residual, activation, MRF running mean, activation-grad masks, FiLM grads).
 #include "conv_common.h"
 
+PROF_DEFINE(tdvc_debug_gemm_prof)
 namespace tdvc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -61,7 +62,10 @@ __device__ __forceinline__ float weight_elem(const GemmConvP& p, int g, int row,
 // PIPE: the input prologue is NONE/LeakyReLU, so interior tiles prefetch their rows into registers one chunk
 // ahead; !PIPE: prologues that read a second/third tensor (FiLM, activation-grad masks) stage in batches.
 template <int MODE, int M_REP, int N_REP, int WM, int WN, bool PIPE>
-__global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 3 : 4)) void conv_gemm_kernel(const GemmConvP p) {
+// (strided / transposed instances hold a prefetched weight tile and a prefetched input tile: 2 blocks = 256 VGPRs (3 = 168 for
+//  the 16-row tiles), no spills;
+//  at 4 blocks they spilled 36-95 registers and every prefetch load was followed by a scratch store that waited for it)
+__global__ __launch_bounds__(256, (MODE != MODE_DIRECT ? (M_REP * WM == 1 ? (N_REP == 1 ? 4 : 3) : (M_REP == 1 && WM == 4 ? 3 : 2)) : (M_REP * N_REP >= 16 ? 3 : 4))) void conv_gemm_kernel(const GemmConvP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int MT = 16 * M_REP * WM;
   constexpr int NT = 16 * N_REP * WN;
@@ -79,6 +83,7 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 3 : 4)) void conv_gemm_
   const int r0 = mt * MT;
   const int Cx_tot = p.groups * p.x.Cg;
   const int i0 = p.i0;
+  PROF_DECL
 
   f32x4 acc[M_REP][N_REP];
 #pragma unroll
@@ -101,31 +106,151 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 3 : 4)) void conv_gemm_
   // Software pipeline over channel chunks (cdna_hip_programming.md T14): the global loads of chunk c+1
   // (input rows and weight rows, both as aligned float4) are issued before the MFMA loop of chunk c and
   // committed to LDS after it, so HBM/L2 latency hides under the matrix work.
-  constexpr int XV = 8;                    // float4 per thread: input rows
+  constexpr int XV = NT <= 64 ? 4 : 8;     // float4 per thread: input rows (64-column tiles: the 16 x 64 one keeps 4 blocks per CU)
   constexpr int WVV = MT >= 64 ? 10 : 6;   // float4 per thread: weight rows
   RegTile<PIPE ? XV : 1> xr;
   RegTile<WVV> wr;
   const int jc = p.J * p.Cc;               // LDS weight row: ws[m][c*J + j]
   const float inv_j = 1.0f / (float)p.J;
-  const bool fast_tile = (MODE != MODE_DOWN) && rows_fast_ok(p.x, n0 + p.lo, p.span);
+  // float4 row tiles: interior tiles, and -- without reflect padding -- the tiles at the sequence ends too (q0 % 4 == 0 and
+  // T % 4 == 0: a float4 column lies wholly inside or wholly outside [0, T) and the outside ones load as zero). Short
+  // sequences (T = 500 on 256-column tiles) consist of end tiles only.
+  const int q0x = n0 + p.lo;
+  const bool fast_tile = (MODE != MODE_DOWN) && rows_align_ok(p.x, q0x, p.span) && ((q0x >= 0 && q0x + p.span <= p.x.T) || !p.reflect);
+  const int vlo = q0x < 0 ? (-q0x) >> 2 : 0, vhi = (p.x.T - q0x) >> 2;
   const bool pipelined = PIPE && fast_tile && p.Cc * (p.span >> 2) <= XV * 256;
   // weights: natural layout (rows contiguous over (c, k)) and 16-byte alignable -> float4 row copies
-  const bool wfast = (MODE == MODE_DIRECT) && p.w_nat && MT * (jc >> 2) <= WVV * 256;
+  const bool wfast = (p.w_packed || (MODE == MODE_DIRECT && p.w_nat)) && MT * (jc >> 2) <= WVV * 256;
   const float* xrow0 = p.x.p + (long)b * p.x.bs + (long)(g * p.x.Cg) * p.x.T + (n0 + p.lo);
   const float* wrow0 = p.w + (long)g * p.w_sg + (long)r0 * p.w_sm;
   const Xf wxf = {XF_NONE, 0.f, 1.f, nullptr, 0};
 
   auto x_issue = [&](int c0) {
-    if (PIPE) tile_issue<PIPE ? XV : 1>(xr, xrow0 + (long)c0 * p.x.T, p.x.T, min(p.Cc, p.Cred - c0), p.Cc, p.span, p.span, 0, tid);
+    if (PIPE) tile_issue<PIPE ? XV : 1>(xr, xrow0 + (long)c0 * p.x.T, p.x.T, min(p.Cc, p.Cred - c0), p.Cc, p.span, p.span, 0, tid, vlo, vhi);
   };
   auto w_issue = [&](int c0) {
-    tile_issue<WVV>(wr, wrow0 + (long)c0 * p.K, (int)p.w_sm, min(MT, p.R - r0), MT, jc, min(p.Cc, p.Cred - c0) * p.J, 0, tid);
+    tile_issue<WVV>(wr, wrow0 + (long)c0 * p.J, (int)p.w_sm, min(MT, p.R - r0), MT, jc, min(p.Cc, ((p.Cred + 3) & ~3) - c0) * p.J, 0, tid);   // (DIRECT: J == K)
+  };
+  // MODE_DOWN, whole channels per chunk (p.chan_stage): coalesced time-to-depth. The s phase rows (c, 0..s-1) of one channel
+  // are the SAME contiguous run of span*s samples x[c][(n0+lo)*s - pad ...], so consecutive lanes read consecutive float4 of
+  // that run (one wide coalesced stream per channel instead of s stride-s gathers) and the de-interleave happens on the way
+  // into LDS: sample e of the run belongs to phase e % s, column e / s. Issue and commit are split like the row tiles above:
+  // a chunk that fits the 8 float4 per thread is prefetched under the previous chunk's MFMAs.
+  const int xd_nvr = (p.span * p.s) >> 2;                         // float4 per channel run
+  const int xd_qbase = (n0 + p.lo) * p.s - p.pad;
+  const srd_t xd_rs = make_srd(p.x.p + (long)b * p.x.bs, Cx_tot * p.x.T * 4);
+  constexpr int XSL = 2;                                          // general form: 2 float4 per thread in flight (rare blocks)
+  f32x4 xt[XSL];
+  auto xd_issue = [&](int c0, int eb) {
+    const int nchv = (min(p.Cred, c0 + p.Cc) - c0) / p.s;          // channels of this chunk that exist
+    const int chan0 = g * p.x.Cg + c0 / p.s, tot = (p.Cc / p.s) * xd_nvr;
+    const float inv_nvr = 1.0f / (float)xd_nvr;
+#pragma unroll
+    for (int i = 0; i < XSL; ++i) {
+      const int e = eb + tid + i * 256;
+      const int ch = (int)(((float)e + 0.5f) * inv_nvr);
+      const int q = xd_qbase + 4 * (e - ch * xd_nvr);
+      const bool ok = e < tot && ch < nchv && q + 3 >= 0 && q < p.x.T;
+      const int off = ((chan0 + ch) * p.x.T + q) * 4;
+      if (ok && q < 0) {                 // straddles position 0: a negative offset fails the range check as a whole (first channel)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          xt[i][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xd_rs, q + k >= 0 ? off + 4 * k : 0x7f000000, 0, 0));
+      } else {
+        xt[i] = buf_load4(xd_rs, ok ? off : 0x7f000000);
+      }
+    }
+  };
+  auto xd_commit = [&](int c0, int eb) {
+    const int nchv = (min(p.Cred, c0 + p.Cc) - c0) / p.s;
+    const int tot = (p.Cc / p.s) * xd_nvr;
+    const float inv_nvr = 1.0f / (float)xd_nvr, inv_s = 1.0f / (float)p.s;
+    const bool act = p.x.xf.kind == XF_LRELU;
+    const float sl = p.x.xf.slope, sc = p.x.xf.scale;
+#pragma unroll
+    for (int i = 0; i < XSL; ++i) {
+      const int e = eb + tid + i * 256;
+      if (e >= tot) continue;
+      const int ch = (int)(((float)e + 0.5f) * inv_nvr);
+      const int ee = 4 * (e - ch * xd_nvr);
+      const int q = xd_qbase + ee;
+      int col = (int)(((float)ee + 0.5f) * inv_s);
+      int phi = ee - col * p.s;
+      float* rows = xs + ch * p.s * p.XS;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float val = xt[i][k];
+        if (act) val = fmaxf(val, val * sl);
+        val = (ch < nchv && q + k >= 0 && q + k < p.x.T) ? val * sc : 0.f;   // a float4 may straddle a row end
+        rows[phi * p.XS + col] = val;
+        if (++phi == p.s) { phi = 0; ++col; }
+      }
+    }
+  };
+  const bool down_chan = PIPE && MODE == MODE_DOWN && p.chan_stage;
+  // Interior blocks whose chunk fits the 8 float4 per thread take the prefetched form with everything that does not depend
+  // on the chunk worked out ONCE per thread: xo[i] = byte offset of slot i's float4 inside the chunk's channels (or the
+  // out-of-range sentinel), xm[i] = LDS destination | valid components << 16 | first phase << 20. Per chunk that leaves one
+  // buffer load per slot and four LDS stores, no index arithmetic and no lane masks (hoisted out of the chunk loop those
+  // cost 340 spilled SGPRs). First tiles whose run starts inside a float4 (pad % 4 != 0) and ragged chunk counts keep the general form.
+  const bool down_pipe = down_chan && (p.Cc / p.s) * xd_nvr <= XV * 256 && (xd_qbase >= 0 || (xd_qbase & 3) == 0) && p.Cred % p.Cc == 0;
+  int xo[XV], xm[XV];
+  const int xd_dump = p.Cc * p.XS - 1;                              // a pad column nobody reads (XS >= span + 12)
+  if (down_pipe) {
+    const int tot = (p.Cc / p.s) * xd_nvr;
+    const float inv_nvr = 1.0f / (float)xd_nvr, inv_s = 1.0f / (float)p.s;
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      xo[i] = 0x7f000000; xm[i] = xd_dump | (1 << 25);
+      if (walk_opaque(i * 256) >= tot) continue;             // (uniform: small chunks fill one or two slots)
+      const int e = tid + i * 256;
+      const int ch = (int)(((float)e + 0.5f) * inv_nvr);
+      const int ee = 4 * (e - ch * xd_nvr);
+      const int q = xd_qbase + ee;
+      const bool ok = e < tot && q >= 0 && q < p.x.T;      // (runs that start before sample 0 do so by whole float4 here)
+      const int col = (int)(((float)ee + 0.5f) * inv_s);
+      const int phi = ee - col * p.s;
+      const int nk = ok ? min(4, p.x.T - q) : 0;
+      xo[i] = ok ? (ch * p.x.T + q) * 4 : 0x7f000000;
+      xm[i] = (e < tot ? ch * p.s * p.XS + phi * p.XS + col : xd_dump) | (nk << 16) | ((e < tot ? phi : 0) << 20) | ((e < tot ? 0 : 1) << 25);
+    }
+  }
+  auto xf_issue = [&](int c0) {
+    const srd_t rs = make_srd(p.x.p + (long)b * p.x.bs + (long)(g * p.x.Cg + c0 / p.s) * p.x.T, (p.Cc / p.s) * p.x.T * 4);
+#pragma unroll
+    for (int i = 0; i < XV; ++i)
+      if (walk_opaque(i * 256) < (p.Cc / p.s) * xd_nvr) xr.v[i] = buf_load4(rs, xo[i]);
+  };
+  auto xf_commit = [&]() {
+    const bool act = p.x.xf.kind == XF_LRELU;
+    const float sl = p.x.xf.slope, sc = p.x.xf.scale;
+    const int wrap = 1 - (p.s - 1) * p.XS;                         // phase s-1 -> phase 0 of the next column
+#pragma unroll
+    for (int i = 0; i < XV; ++i) {
+      if (walk_opaque(i * 256) >= (p.Cc / p.s) * xd_nvr) break;
+      int dst = xm[i] & 0xffff;
+      const int nk = (xm[i] >> 16) & 15;
+      int phi = (xm[i] >> 20) & 31;
+      const bool dead = (xm[i] >> 25) & 1;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float val = xr.v[i][k];
+        if (act) val = fmaxf(val, val * sl);
+        xs[dst] = k < nk ? val * sc : 0.f;
+        const bool w = phi + 1 == p.s;
+        dst = dead ? xd_dump : dst + (w ? wrap : p.XS);          // slots past the chunk keep writing the one pad word
+        phi = w ? 0 : phi + 1;
+      }
+    }
   };
   if (pipelined) x_issue(0);
+  if (down_pipe) xf_issue(0);
   if (wfast) w_issue(0);
 
+  PROF(0)
   for (int c0 = 0; c0 < p.Cred; c0 += p.Cc) {
     __syncthreads();                       // every wave is done reading the previous chunk
+    PROF(1)
     // ---- X' chunk -> LDS
     if (pipelined) {
       tile_commit<PIPE ? XV : 1>(xr, nullptr, nullptr, p.x.xf, xs, p.XS, min(p.Cc, p.Cred - c0), p.Cc, p.span, 0, tid);
@@ -144,60 +269,98 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 3 : 4)) void conv_gemm_
         }
         xs[r * p.XS + i] = v;
       }
+    } else if (down_chan) {
+      if (down_pipe) {
+        xf_commit();
+      } else {
+        const int tot = (p.Cc / p.s) * xd_nvr;
+        for (int eb = 0; eb < tot; eb += XSL * 256) { xd_issue(c0, eb); xd_commit(c0, eb); }
+      }
     } else if (MODE == MODE_DOWN && p.chan_stage) {
-      // Coalesced time-to-depth: the s phase rows (c, 0..s-1) of one channel are the SAME contiguous run of span*s
-      // samples x[c][(n0+lo)*s - pad ...], so consecutive lanes read consecutive samples (one wide coalesced stream per
-      // channel instead of s stride-s gathers) and the de-interleave happens on the way into LDS: sample e of the run
-      // belongs to phase e % s, column e / s.
+      // prologues with a second tensor (activation-grad masks): element-wise
       const int nch = p.Cc / p.s, len = p.span * p.s;
-      const long qbase = (long)(n0 + p.lo) * p.s - p.pad;
+      const int nchv = (min(p.Cred, c0 + p.Cc) - c0) / p.s;
+      const int chan0 = g * p.x.Cg + c0 / p.s;
       const float inv_s = 1.0f / (float)p.s;
       for (int ch = 0; ch < nch; ++ch) {
-        const int cr = c0 + ch * p.s;
-        const bool rv = cr < p.Cred;
-        const int chan = g * p.x.Cg + cr / p.s;
+        const bool rv = ch < nchv;
         float* rows = xs + ch * p.s * p.XS;
         for (int e = tid; e < len; e += 256) {
           const int i = (int)(((float)e + 0.5f) * inv_s);
           const int phi = e - i * p.s;
-          rows[phi * p.XS + i] = rv ? fetch_opnd(p.x, b, chan, (int)(qbase + e), 0, Cx_tot) : 0.f;
+          rows[phi * p.XS + i] = rv ? fetch_opnd(p.x, b, chan0 + ch, xd_qbase + e, 0, Cx_tot) : 0.f;
         }
       }
     } else if (!PIPE && fast_tile) {
-      stage_rows_batched<4>(p.x, xs, p.XS, b, g * p.x.Cg + c0, min(p.Cc, p.Cred - c0), p.Cc, n0 + p.lo, p.span, Cx_tot, tid);
+      stage_rows_batched<4>(p.x, xs, p.XS, b, g * p.x.Cg + c0, min(p.Cc, p.Cred - c0), p.Cc, n0 + p.lo, p.span, Cx_tot, tid, vlo, vhi);
     } else {
-      for (int r = wave; r < p.Cc; r += 4) {
-        const int cr = c0 + r;
-        const bool rv = cr < p.Cred;
-        int ch, phi = 0;
-        if (MODE == MODE_DOWN) { int c = cr / p.s; phi = cr - c * p.s; ch = g * p.x.Cg + c; }
-        else ch = g * p.x.Cg + cr;
-        float* row = xs + r * p.XS;
-        for (int i = lane; i < p.span; i += 64) {
-          const int xi = n0 + p.lo + i;
+      // any mode, any position (sequence ends, short sequences): element-wise with the full padding logic, 8 elements per
+      // thread in flight
+      constexpr int SB = MODE == MODE_DIRECT ? 4 : 8;       // (the DIRECT instances already sit at their register cap)
+      const int tot = p.Cc * p.span;
+      const float inv_span = 1.0f / (float)p.span;
+      for (int eb = 0; eb < tot; eb += SB * 256) {
+        float v[SB];
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+          const int e = eb + tid + i * 256;
+          const int r = (int)(((float)e + 0.5f) * inv_span);
+          const int ii = e - r * p.span;
+          const int cr = c0 + r;
+          int ch, phi = 0;
+          if (MODE == MODE_DOWN) { int c = cr / p.s; phi = cr - c * p.s; ch = g * p.x.Cg + c; }
+          else ch = g * p.x.Cg + cr;
+          const int xi = n0 + p.lo + ii;
           const int q = (MODE == MODE_DOWN) ? xi * p.s + phi - p.pad : xi;
-          row[i] = rv ? fetch_opnd(p.x, b, ch, q, p.reflect, Cx_tot) : 0.f;
+          v[i] = (e < tot && cr < p.Cred) ? fetch_opnd(p.x, b, ch, q, p.reflect, Cx_tot) : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < SB; ++i) {
+          const int e = eb + tid + i * 256;
+          if (e >= tot) continue;
+          const int r = (int)(((float)e + 0.5f) * inv_span);
+          xs[r * p.XS + (e - r * p.span)] = v[i];
         }
       }
     }
+    PROF(2)
     // ---- A chunk -> LDS, ws[m][c*J + j]
     if (wfast) {
       tile_commit<WVV>(wr, nullptr, nullptr, wxf, ws, p.WS, min(MT, p.R - r0), MT, jc, 0, tid);
     } else {
-      for (int m = wave; m < MT; m += 4) {
-        float* row = ws + m * p.WS;
-        for (int idx = lane; idx < jc; idx += 64) {
+      // reduced-layout gather (strided / transposed / grouped weights): 8 elements per thread in flight
+      constexpr int WB = MODE == MODE_DIRECT ? 4 : 8;
+      const int wtot = MT * jc;
+      const float inv_jc = 1.0f / (float)jc;
+      for (int eb = 0; eb < wtot; eb += WB * 256) {
+        float wv[WB];
+#pragma unroll
+        for (int i = 0; i < WB; ++i) {
+          const int e = eb + tid + i * 256;
+          const int m = (int)(((float)e + 0.5f) * inv_jc);
+          const int idx = e - m * jc;
           const int c = (int)(((float)idx + 0.5f) * inv_j);
-          row[idx] = weight_elem<MODE>(p, g, r0 + m, c0 + c, idx - c * p.J);
+          wv[i] = e < wtot ? weight_elem<MODE>(p, g, r0 + m, c0 + c, idx - c * p.J) : 0.f;
+        }
+#pragma unroll
+        for (int i = 0; i < WB; ++i) {
+          const int e = eb + tid + i * 256;
+          if (e >= wtot) continue;
+          const int m = (int)(((float)e + 0.5f) * inv_jc);
+          ws[m * p.WS + (e - m * jc)] = wv[i];
         }
       }
     }
+    PROF(8)
     __syncthreads();
+    PROF(3)
     if (c0 + p.Cc < p.Cred) {              // next chunk's loads fly while this chunk's MFMAs run
       if (pipelined) x_issue(c0 + p.Cc);
+      if (down_pipe) xf_issue(c0 + p.Cc);
       if (wfast) w_issue(c0 + p.Cc);
     }
 
+    PROF(4)
     // ---- MFMA main loop: K dimension = (tap j, channel c); each 16x16x4 step takes 4 channels of one tap
     const int csteps = p.Cc >> 2;
     const float* a_base = ws + (wrow0_l + ln) * p.WS + kq * p.J;
@@ -214,8 +377,12 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 3 : 4)) void conv_gemm_
 #pragma unroll
         for (int m = 0; m < M_REP; ++m)
 #pragma unroll
-          for (int n = 0; n < N_REP; ++n)
-            acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv[n], acc[m][n], 0, 0, 0);
+          for (int n = 0; n < N_REP; ++n) {
+            // MODE_DOWN computes the transposed tile (operands swapped: same registers): a lane then holds four CONSECUTIVE
+            // columns of one row, which the epilogue stores as one float4 along time
+            if (MODE == MODE_DOWN) acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(bv[n], a[m], acc[m][n], 0, 0, 0);
+            else acc[m][n] = __builtin_amdgcn_mfma_f32_16x16x4f32(a[m], bv[n], acc[m][n], 0, 0, 0);
+          }
       }
     }
 
@@ -251,10 +418,59 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 3 : 4)) void conv_gemm_
         }
       }
     }
+    PROF(5)
   }
 
   // ---- epilogue: C/D layout col = lane&15, row = (lane>>4)*4 + reg
   const int Cy_tot = p.groups * p.Cy_g;
+  if (MODE == MODE_DOWN) {
+    // transposed tile: lane (ln, kq) holds row ln, columns kq*4 .. kq*4+3
+    const bool vec = (p.Ty & 3) == 0 && (p.y_bs & 3) == 0 && (((uintptr_t)p.y) & 15) == 0 && !p.bias3 && p.epi != EPI_FILM &&
+                     (!p.res || ((p.res_bs & 3) == 0 && (((uintptr_t)p.res) & 15) == 0)) &&
+                     (!p.add || ((p.add_bs & 3) == 0 && (((uintptr_t)p.add) & 15) == 0)) &&
+                     (p.epi != EPI_MASK || ((p.mx_bs & 3) == 0 && (((uintptr_t)p.mx) & 15) == 0));
+#pragma unroll
+    for (int m = 0; m < M_REP; ++m) {
+      const int row = r0 + wrow0_l + m * 16 + ln;
+      if (row >= p.R) continue;
+      const int ch = g * p.Cy_g + row;
+      const float bias = (p.epi == EPI_FWD && p.bias) ? p.bias[ch] : 0.f;
+#pragma unroll
+      for (int n = 0; n < N_REP; ++n) {
+        const int u0 = n0 + wcol0 + n * 16 + kq * 4;
+        if (u0 >= p.N) continue;
+        f32x4 v = acc[m][n];
+        if (vec && u0 + 3 < p.N) {
+          const long oi = (long)ch * p.Ty + u0;
+          if (p.epi == EPI_FWD) {
+            v += bias;
+            if (p.res) v += *reinterpret_cast<const f32x4*>(p.res + (long)b * p.res_bs + oi);
+            if (p.post == POST_LRELU) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] = lrelu_f(v[q], p.post_slope);
+            } else if (p.post == POST_TANH) {
+#pragma unroll
+              for (int q = 0; q < 4; ++q) v[q] = tanhf(v[q]);
+            }
+            v *= p.out_scale;
+          } else if (p.epi == EPI_MASK) {
+            const f32x4 mm = *reinterpret_cast<const f32x4*>(p.mx + (long)b * p.mx_bs + oi);
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = mm[q] > 0.f ? v[q] : v[q] * p.m_slope;
+          }
+          if (p.add) v += p.add_scale * *reinterpret_cast<const f32x4*>(p.add + (long)b * p.add_bs + oi);
+          *reinterpret_cast<f32x4*>(p.y + (long)b * p.y_bs + oi) = v;
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q)
+            if (u0 + q < p.N) conv_epilogue(p, v[q], b, ch, u0 + q, Cy_tot);
+        }
+      }
+    }
+    PROF(6)
+    PROF_END
+    return;
+  }
   if (MODE == MODE_UP && (p.s == 4 || p.s == 8) && (p.epi == EPI_PLAIN || p.epi == EPI_MASK) && !p.add && (p.pad & 3) == 0 && (p.Ty & 3) == 0 &&
       (p.y_bs & 3) == 0 && (((uintptr_t)p.y) & 15) == 0 && (p.epi == EPI_PLAIN || ((p.mx_bs & 3) == 0 && (((uintptr_t)p.mx) & 15) == 0))) {
     // Depth-to-time with stride 4 / 8: the lane's four accumulator rows are four CONSECUTIVE phases of one output channel,
@@ -287,6 +503,8 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 3 : 4)) void conv_gemm_
         }
       }
     }
+    PROF(6)
+    PROF_END
     return;
   }
 #pragma unroll
@@ -309,6 +527,8 @@ __global__ __launch_bounds__(256, (M_REP * N_REP >= 16 ? 3 : 4)) void conv_gemm_
       }
     }
   }
+  PROF(6)
+  PROF_END
 }
 
 // ----------------------------------------------------------------------------------------------
@@ -540,11 +760,55 @@ __global__ __launch_bounds__(256) void conv_wgrad_scalar_kernel(const WgradP p, 
   if (threadIdx.x == 0) dw[(long)g * p.w_sg + (long)row * p.w_sm + (long)c * p.w_sc + k] += sh[0] + sh[1] + sh[2] + sh[3];
 }
 
+// ----------------------------------------------------------------------------------------------
+// Reduced-layout weight copy for the strided / transposed / grouped problems: dst[g][r][cr][j] = A[r][cr][j] of group g,
+// reduced channels padded to a multiple of 4 with zeros. The conv kernel then copies weight rows as float4, prefetched one
+// chunk ahead, instead of gathering them element by element (index arithmetic + a dependent L2 round trip per batch) in
+// every block and chunk: that gather was 50 % of the block time of the 64 -> 128 stride-8 conv (profiles/r02_f_*).
+template <int MODE>
+__global__ __launch_bounds__(256) void weight_repack_kernel(const GemmConvP p, float* dst, int Cred4, long total) {
+  for (long i = blockIdx.x * 256L + threadIdx.x; i < total; i += gridDim.x * 256L) {
+    const int j = (int)(i % p.J);
+    long t = i / p.J;
+    const int cr = (int)(t % Cred4);
+    t /= Cred4;
+    const int r = (int)(t % p.R), g = (int)(t / p.R);
+    dst[i] = weight_elem<MODE>(p, g, r, cr, j);
+  }
+}
+
 }  // namespace tdvc
 
 // ================================================================================================
 // host-side launchers (called from conv_api.cpp)
+#include <map>
 namespace tdvc {
+
+// Scratch for the repacked weights of ONE launch, per stream: repack -> conv -> next repack are ordered by the stream, so
+// one buffer per stream is enough. Buffers are allocated outside graph capture only (the eager warm-up step sizes them) and
+// never freed or moved, because a captured graph holds their address. A stream first seen DURING capture (torch captures on
+// a side stream of its own) borrows the buffer the warm-up made on another stream: the capture stream and the warm-up
+// stream never run convs at the same time. nullptr = no buffer can be had: the caller keeps the in-kernel gather.
+static float* weight_scratch(hipStream_t st, size_t bytes) {
+  static std::mutex mu;
+  static std::map<hipStream_t, std::pair<float*, size_t>> pool;
+  std::lock_guard<std::mutex> lk(mu);
+  auto it = pool.find(st);
+  if (it != pool.end() && it->second.second >= bytes) return it->second.first;
+  hipStreamCaptureStatus cs = hipStreamCaptureStatusNone;
+  const bool capturing = hipStreamIsCapturing(st, &cs) != hipSuccess || cs != hipStreamCaptureStatusNone;
+  (void)hipGetLastError();
+  if (capturing) {
+    for (auto& kv : pool)
+      if (kv.second.second >= bytes) { pool[st] = kv.second; return kv.second.first; }
+    return nullptr;
+  }
+  size_t nb = bytes < ((size_t)8 << 20) ? ((size_t)8 << 20) : (bytes + ((size_t)1 << 20) - 1) / ((size_t)1 << 20) * ((size_t)1 << 20);
+  float* nbuf = nullptr;
+  if (hipMalloc(&nbuf, nb) != hipSuccess) { (void)hipGetLastError(); return nullptr; }
+  pool[st] = std::make_pair(nbuf, nb);          // an outgrown buffer stays allocated: a captured graph may still point at it
+  return nbuf;
+}
 
 template <int MODE, int M_REP, int N_REP, int WM, int WN, bool PIPE>
 static hipError_t launch_gemm_cfg2(const GemmConvP& p, int B, hipStream_t st) {
@@ -612,6 +876,19 @@ hipError_t launch_conv_gemm(GemmConvP p, int B, hipStream_t st) {
   p.WS = p.J * Cc + 2;                      // WS/2 odd: 16 rows x 2 k-lanes hit 32 distinct banks (odd J)
   p.w_nat = (MODE == MODE_DIRECT && p.w_sc == p.K && (p.w_sm & 3) == 0 && (p.w_sg & 3) == 0 && (p.Cred & 3) == 0 &&
              (((uintptr_t)p.w) & 15) == 0) ? 1 : 0;
+  p.w_packed = 0;
+  if (!p.w_nat && g_knob[1] == 0) {
+    const int Cred4 = (p.Cred + 3) / 4 * 4;
+    const long total = (long)p.groups * p.R * Cred4 * p.J;
+    float* scr = weight_scratch(st, (size_t)total * sizeof(float));
+    if (scr) {
+      auto rk = weight_repack_kernel<MODE>;
+      TDVC_TRACE(rk);
+      long gx = (total + 255) / 256; if (gx > 2048) gx = 2048;
+      hipLaunchKernelGGL(rk, dim3((unsigned)gx), dim3(256), 0, st, p, scr, Cred4, total);
+      p.w = scr; p.w_sg = (long)p.R * Cred4 * p.J; p.w_sm = (long)Cred4 * p.J; p.w_sc = p.J; p.w_packed = 1;
+    }
+  }
   switch (cfg) {
     case 0: return launch_gemm_cfg<MODE, 1, 4, 1, 4>(p, B, st);
     case 1: return launch_gemm_cfg<MODE, 2, 4, 1, 4>(p, B, st);
