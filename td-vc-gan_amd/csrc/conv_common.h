@@ -305,6 +305,57 @@ __device__ __forceinline__ void stage_rows_batched(const Opnd& o, float* dst, in
 }
 
 
+// MODE_DOWN staging, general form (any position, prologue NONE / LeakyReLU): the s phase rows (c, 0..s-1) of one channel are
+// the SAME contiguous run of span*s samples x[c][qbase ...], read as float4 by consecutive lanes and de-interleaved on the
+// way into LDS (sample e of the run -> phase e % s, column e / s). NB float4 per thread are in flight before the first LDS
+// store. xs rows: [nch * s][XS]; channels >= nchv and samples outside [0, T) are written as zero.
+template <int NB>
+__device__ __forceinline__ void stage_down_runs(const Opnd& o, float* xs, int XS, int b, int chan0, int nch, int nchv, int s, int qbase,
+                                                int span, int Ctot, int tid) {
+  const int nvr = (span * s) >> 2, tot = nch * nvr;
+  const float inv_nvr = 1.0f / (float)nvr, inv_s = 1.0f / (float)s;
+  const srd_t rs = make_srd(o.p + (long)b * o.bs, Ctot * o.T * 4);
+  const bool act = o.xf.kind == XF_LRELU;
+  const float sl = o.xf.slope, sc = o.xf.scale;
+  for (int eb = 0; eb < tot; eb += NB * 256) {
+    f32x4_t v[NB];
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = eb + tid + i * 256;
+      const int ch = (int)(((float)e + 0.5f) * inv_nvr);
+      const int q = qbase + 4 * (e - ch * nvr);
+      const bool ok = e < tot && ch < nchv && q + 3 >= 0 && q < o.T;
+      const int off = ((chan0 + ch) * o.T + q) * 4;
+      if (ok && q < 0) {                 // straddles position 0: a negative offset fails the range check as a whole (first channel)
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          v[i][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rs, q + k >= 0 ? off + 4 * k : 0x7f000000, 0, 0));
+      } else {
+        v[i] = buf_load4(rs, ok ? off : 0x7f000000);
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < NB; ++i) {
+      const int e = eb + tid + i * 256;
+      if (e >= tot) continue;
+      const int ch = (int)(((float)e + 0.5f) * inv_nvr);
+      const int ee = 4 * (e - ch * nvr);
+      const int q = qbase + ee;
+      int col = (int)(((float)ee + 0.5f) * inv_s);
+      int phi = ee - col * s;
+      float* rows = xs + ch * s * XS;
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        float val = v[i][k];
+        if (act) val = fmaxf(val, val * sl);
+        val = (ch < nchv && q + k >= 0 && q + k < o.T) ? val * sc : 0.f;   // a float4 may straddle a row end
+        rows[phi * XS + col] = val;
+        if (++phi == s) { phi = 0; ++col; }
+      }
+    }
+  }
+}
+
 // Scalar (dword) register tile with full padding logic: used for short / unaligned sequences (T = 50, 63, ...) and
 // for the chunks at the sequence ends, so that those too are prefetched one chunk ahead instead of being staged
 // element by element. Supports the prologues NONE / LRELU (aux unused) and MASK_LRELU (aux = activation output).

@@ -138,55 +138,6 @@ __global__ __launch_bounds__(256, (MODE != MODE_DIRECT ? (M_REP * WM == 1 ? (N_R
   // a chunk that fits the 8 float4 per thread is prefetched under the previous chunk's MFMAs.
   const int xd_nvr = (p.span * p.s) >> 2;                         // float4 per channel run
   const int xd_qbase = (n0 + p.lo) * p.s - p.pad;
-  const srd_t xd_rs = make_srd(p.x.p + (long)b * p.x.bs, Cx_tot * p.x.T * 4);
-  constexpr int XSL = 2;                                          // general form: 2 float4 per thread in flight (rare blocks)
-  f32x4 xt[XSL];
-  auto xd_issue = [&](int c0, int eb) {
-    const int nchv = (min(p.Cred, c0 + p.Cc) - c0) / p.s;          // channels of this chunk that exist
-    const int chan0 = g * p.x.Cg + c0 / p.s, tot = (p.Cc / p.s) * xd_nvr;
-    const float inv_nvr = 1.0f / (float)xd_nvr;
-#pragma unroll
-    for (int i = 0; i < XSL; ++i) {
-      const int e = eb + tid + i * 256;
-      const int ch = (int)(((float)e + 0.5f) * inv_nvr);
-      const int q = xd_qbase + 4 * (e - ch * xd_nvr);
-      const bool ok = e < tot && ch < nchv && q + 3 >= 0 && q < p.x.T;
-      const int off = ((chan0 + ch) * p.x.T + q) * 4;
-      if (ok && q < 0) {                 // straddles position 0: a negative offset fails the range check as a whole (first channel)
-#pragma unroll
-        for (int k = 0; k < 4; ++k)
-          xt[i][k] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xd_rs, q + k >= 0 ? off + 4 * k : 0x7f000000, 0, 0));
-      } else {
-        xt[i] = buf_load4(xd_rs, ok ? off : 0x7f000000);
-      }
-    }
-  };
-  auto xd_commit = [&](int c0, int eb) {
-    const int nchv = (min(p.Cred, c0 + p.Cc) - c0) / p.s;
-    const int tot = (p.Cc / p.s) * xd_nvr;
-    const float inv_nvr = 1.0f / (float)xd_nvr, inv_s = 1.0f / (float)p.s;
-    const bool act = p.x.xf.kind == XF_LRELU;
-    const float sl = p.x.xf.slope, sc = p.x.xf.scale;
-#pragma unroll
-    for (int i = 0; i < XSL; ++i) {
-      const int e = eb + tid + i * 256;
-      if (e >= tot) continue;
-      const int ch = (int)(((float)e + 0.5f) * inv_nvr);
-      const int ee = 4 * (e - ch * xd_nvr);
-      const int q = xd_qbase + ee;
-      int col = (int)(((float)ee + 0.5f) * inv_s);
-      int phi = ee - col * p.s;
-      float* rows = xs + ch * p.s * p.XS;
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        float val = xt[i][k];
-        if (act) val = fmaxf(val, val * sl);
-        val = (ch < nchv && q + k >= 0 && q + k < p.x.T) ? val * sc : 0.f;   // a float4 may straddle a row end
-        rows[phi * p.XS + col] = val;
-        if (++phi == p.s) { phi = 0; ++col; }
-      }
-    }
-  };
   const bool down_chan = PIPE && MODE == MODE_DOWN && p.chan_stage;
   // Interior blocks whose chunk fits the 8 float4 per thread take the prefetched form with everything that does not depend
   // on the chunk worked out ONCE per thread: xo[i] = byte offset of slot i's float4 inside the chunk's channels (or the
@@ -273,8 +224,8 @@ __global__ __launch_bounds__(256, (MODE != MODE_DIRECT ? (M_REP * WM == 1 ? (N_R
       if (down_pipe) {
         xf_commit();
       } else {
-        const int tot = (p.Cc / p.s) * xd_nvr;
-        for (int eb = 0; eb < tot; eb += XSL * 256) { xd_issue(c0, eb); xd_commit(c0, eb); }
+        stage_down_runs<2>(p.x, xs, p.XS, b, g * p.x.Cg + c0 / p.s, p.Cc / p.s, (min(p.Cred, c0 + p.Cc) - c0) / p.s, p.s, xd_qbase, p.span,
+                           Cx_tot, tid);
       }
     } else if (MODE == MODE_DOWN && p.chan_stage) {
       // prologues with a second tensor (activation-grad masks): element-wise
@@ -471,8 +422,9 @@ __global__ __launch_bounds__(256, (MODE != MODE_DIRECT ? (M_REP * WM == 1 ? (N_R
     PROF_END
     return;
   }
-  if (MODE == MODE_UP && (p.s == 4 || p.s == 8) && (p.epi == EPI_PLAIN || p.epi == EPI_MASK) && !p.add && (p.pad & 3) == 0 && (p.Ty & 3) == 0 &&
-      (p.y_bs & 3) == 0 && (((uintptr_t)p.y) & 15) == 0 && (p.epi == EPI_PLAIN || ((p.mx_bs & 3) == 0 && (((uintptr_t)p.mx) & 15) == 0))) {
+  const bool up_epi_ok = (p.epi == EPI_PLAIN || p.epi == EPI_MASK || (p.epi == EPI_FWD && !p.res && !p.bias3)) && !p.add;
+  if (MODE == MODE_UP && (p.s == 4 || p.s == 8) && up_epi_ok && (p.pad & 3) == 0 && (p.Ty & 3) == 0 &&
+      (p.y_bs & 3) == 0 && (((uintptr_t)p.y) & 15) == 0 && (p.epi != EPI_MASK || ((p.mx_bs & 3) == 0 && (((uintptr_t)p.mx) & 15) == 0))) {
     // Depth-to-time with stride 4 / 8: the lane's four accumulator rows are four CONSECUTIVE phases of one output channel,
     // i.e. four consecutive output samples u0 .. u0+3 with u0 % 4 == 0 -> one dwordx4 store per 16x16 tile and lane
     // (consecutive lanes = consecutive columns = consecutive float4) instead of four stride-s scalar stores.
@@ -482,6 +434,7 @@ __global__ __launch_bounds__(256, (MODE != MODE_DIRECT ? (M_REP * WM == 1 ? (N_R
       if (row0 >= p.R) continue;
       const int mm = row0 / p.s, phi0 = row0 - mm * p.s;
       const long rbase = (long)(g * p.Cy_g + mm) * p.Ty;
+      const float bias = (p.epi == EPI_FWD && p.bias) ? p.bias[g * p.Cy_g + mm] : 0.f;
 #pragma unroll
       for (int n = 0; n < N_REP; ++n) {
         const int col = n0 + wcol0 + n * 16 + ln;
@@ -494,12 +447,62 @@ __global__ __launch_bounds__(256, (MODE != MODE_DIRECT ? (M_REP * WM == 1 ? (N_R
             const f32x4 mm4 = *reinterpret_cast<const f32x4*>(p.mx + (long)b * p.mx_bs + rbase + u0);
 #pragma unroll
             for (int q = 0; q < 4; ++q) v[q] = mm4[q] > 0.f ? v[q] : v[q] * p.m_slope;
+          } else if (p.epi == EPI_FWD) {
+            v += bias;
+#pragma unroll
+            for (int q = 0; q < 4; ++q) v[q] = p.post == POST_LRELU ? lrelu_f(v[q], p.post_slope) : (p.post == POST_TANH ? tanhf(v[q]) : v[q]);
+            v *= p.out_scale;
           }
           *reinterpret_cast<f32x4*>(p.y + (long)b * p.y_bs + rbase + u0) = v;
         } else {
 #pragma unroll
           for (int q = 0; q < 4; ++q)
             if (u0 + q >= 0 && u0 + q < p.Ty) conv_epilogue(p, v[q], b, g * p.Cy_g + mm, u0 + q, Cy_tot);
+        }
+      }
+    }
+    PROF(6)
+    PROF_END
+    return;
+  }
+  if (MODE == MODE_UP && p.s == 2 && up_epi_ok && (p.R & 3) == 0) {
+    // stride 2: the lane's four rows are (channel mm, phases 0 1) and (channel mm + 1, phases 0 1): two float2 stores
+    // (8 bytes at 4-byte alignment when the padding is odd); 16 lanes = 16 consecutive float2 of one channel
+    typedef float f32x2 __attribute__((ext_vector_type(2)));
+#pragma unroll
+    for (int m = 0; m < M_REP; ++m) {
+      const int row0 = r0 + wrow0_l + m * 16 + kq * 4;
+      if (row0 >= p.R) continue;
+      const int mm0 = row0 >> 1;
+#pragma unroll
+      for (int n = 0; n < N_REP; ++n) {
+        const int col = n0 + wcol0 + n * 16 + ln;
+        if (col >= p.N) continue;
+        const int u0 = col * 2 - p.pad;
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+          const int ch = g * p.Cy_g + mm0 + h;
+          f32x2 v = {acc[m][n][2 * h], acc[m][n][2 * h + 1]};
+          if (u0 >= 0 && u0 + 1 < p.Ty) {
+            const long oi = (long)ch * p.Ty + u0;
+            if (p.epi == EPI_MASK) {
+              const f32x2 m2 = *reinterpret_cast<const f32x2*>(p.mx + (long)b * p.mx_bs + oi);
+              v[0] = m2[0] > 0.f ? v[0] : v[0] * p.m_slope; v[1] = m2[1] > 0.f ? v[1] : v[1] * p.m_slope;
+            } else if (p.epi == EPI_FWD) {
+              const float bias = p.bias ? p.bias[ch] : 0.f;
+#pragma unroll
+              for (int q = 0; q < 2; ++q) {
+                float t = v[q] + bias;
+                t = p.post == POST_LRELU ? lrelu_f(t, p.post_slope) : (p.post == POST_TANH ? tanhf(t) : t);
+                v[q] = t * p.out_scale;
+              }
+            }
+            *reinterpret_cast<f32x2*>(p.y + (long)b * p.y_bs + oi) = v;
+          } else {
+#pragma unroll
+            for (int q = 0; q < 2; ++q)
+              if (u0 + q >= 0 && u0 + q < p.Ty) conv_epilogue(p, v[q], b, ch, u0 + q, Cy_tot);
+          }
         }
       }
     }
@@ -607,8 +610,8 @@ __global__ __launch_bounds__(256, (M_REP * J >= 14 ? 3 : 4)) void conv_wgrad_ker
   const int b_lo = bg * bpb, b_hi = min(B, b_lo + bpb);
   for (int b = b_lo; b < b_hi; ++b) {
     __syncthreads();
-    if (nc0 + p.NTc <= p.N && rows_fast_ok(p.a, nc0, p.NTc)) {
-      stage_rows_batched<8>(p.a, as, p.AS, b, g * p.a.Cg + r0, min(MT, p.R - r0), MT, nc0, p.NTc, Ca_tot, tid);
+    if (rows_align_ok(p.a, nc0, p.NTc) && p.N == p.a.T) {   // float4 rows; the chunk past the sequence end loads zeros
+      stage_rows_batched<8>(p.a, as, p.AS, b, g * p.a.Cg + r0, min(MT, p.R - r0), MT, nc0, p.NTc, Ca_tot, tid, 0, (p.a.T - nc0) >> 2);
     } else {
       for (int m = wave; m < MT; m += 4) {
         const int row = r0 + m;
@@ -620,8 +623,14 @@ __global__ __launch_bounds__(256, (M_REP * J >= 14 ? 3 : 4)) void conv_wgrad_ker
         }
       }
     }
-    if (MODE != MODE_DOWN && rows_fast_ok(p.x, nc0 + p.lo, p.span)) {
-      stage_rows_batched<8>(p.x, xs, p.XS, b, g * p.x.Cg + c0, min(16, p.Cred - c0), 16, nc0 + p.lo, p.span, Cx_tot, tid);
+    const int qx = nc0 + p.lo;
+    if (MODE != MODE_DOWN && rows_align_ok(p.x, qx, p.span) && ((qx >= 0 && qx + p.span <= p.x.T) || !p.reflect)) {
+      stage_rows_batched<8>(p.x, xs, p.XS, b, g * p.x.Cg + c0, min(16, p.Cred - c0), 16, qx, p.span, Cx_tot, tid, qx < 0 ? (-qx) >> 2 : 0,
+                            (p.x.T - qx) >> 2);
+    } else if (MODE == MODE_DOWN && (16 % p.s) == 0 && p.x.xf.kind <= XF_LRELU) {
+      // coalesced time-to-depth (see conv_gemm_kernel): the 16 reduced rows are 16/s whole channels
+      stage_down_runs<4>(p.x, xs, p.XS, b, g * p.x.Cg + c0 / p.s, 16 / p.s, (min(p.Cred, c0 + 16) - c0) / p.s, p.s, qx * p.s - p.pad, p.span,
+                         Cx_tot, tid);
     } else if (MODE == MODE_DOWN && (16 % p.s) == 0) {
       // coalesced time-to-depth (see conv_gemm_kernel): the 16 reduced rows are 16/s whole channels
       const int nch = 16 / p.s, len = p.span * p.s;
@@ -858,18 +867,22 @@ hipError_t launch_conv_gemm(GemmConvP p, int B, hipStream_t st) {
   int Cc = unit;
   while (true) {
     int next = Cc + unit;
-    if (next > 32 || next > ((p.Cred + unit - 1) / unit) * unit) break;
+    // (16-row tiles do 1-4 MFMAs per reduction step and wave: a longer chunk keeps the barrier count of long reductions down)
+    if (next > (MT == 16 ? 64 : 32) || next > ((p.Cred + unit - 1) / unit) * unit) break;
     size_t lds = (size_t)(next * p.XS + MT * (p.J * next + 2)) * 4;
     if (lds > 60 * 1024) break;
-    // keep the chunk inside the kernels' register-prefetch budgets (8 float4 of input, 24/36 weights per thread)
-    if (Cc >= 8 && ((long)next * (p.span >> 2) > 8 * 256 || (long)MT * p.J * next > (MT >= 64 ? 10 : 6) * 1024)) break;
+    // keep the chunk inside the kernels' register-prefetch budgets (4 / 8 float4 of input, 24/36 weights per thread)
+    if (Cc >= 8 && ((long)next * (p.span >> 2) > (NT <= 64 ? 4 : 8) * 256 || (long)MT * p.J * next > (MT >= 64 ? 10 : 6) * 1024)) break;
     Cc = next;
   }
   p.chan_stage = 0;
   if (MODE == MODE_DOWN && !p.stage_rows) {   // whole channels per chunk -> coalesced time-to-depth staging (kernel)
     int unit_s = p.s;                         // lcm(4, s)
     while (unit_s % 4) unit_s += p.s;
-    if (Cc >= unit_s) { Cc = Cc / unit_s * unit_s; p.chan_stage = 1; }
+    if (Cc >= unit_s) {
+      Cc = Cc / unit_s * unit_s; p.chan_stage = 1;
+      while (Cc > unit_s && p.Cred % Cc != 0) Cc -= unit_s;   // equal chunks: the prefetched staging needs Cred % Cc == 0
+    }
     else if (((p.Cred + 3) / 4) * 4 == Cc && Cc % p.s == 0) p.chan_stage = 1;   // the whole reduction in one chunk
   }
   p.Cc = Cc;
