@@ -186,7 +186,8 @@ def kernel_table(pkg, dev, B, step_ms, iters=40, manifest=None):
         bufs = Bufs(torch, dev, dict(dcv=(Bc, nc, T), exc=(Bc, nv, T), dexc=(Bc, nv, T), dk3=(Bc, nc, 3)))
         keep.append(bufs)
         nbytes = lib.tdvc_film_cond0_bwd_workspace(Bc, T, nc, nv)
-        ws = ops.workspace(dev, nbytes)
+        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+        keep.append(ws)
         st = torch.cuda.current_stream(dev).cuda_stream
         calls = []
         for s in bufs.sets:
@@ -194,7 +195,7 @@ def kernel_table(pkg, dev, B, step_ms, iters=40, manifest=None):
                                    s['dexc'].data_ptr(), s['dexc'].stride(0), s['dk3'].data_ptr(), dw0.data_ptr(), ws.data_ptr(),
                                    ws.numel() * ws.element_size())
             keep.append(a)
-            calls.append(lambda a=a: L.check(lib.tdvc_film_cond0_bwd(C.byref(a), st)))
+            calls.append(lambda a=a: (L.check(lib.tdvc_film_cond0_bwd(C.byref(a), st)), L.check(lib.tdvc_fold_flush(st))))
         add(label, n, 'hbm', 4.0 * Bc * T * (nc + 2 * nv), 2.0 * Bc * T * nc * nv * 3 * 2, calls, bufs.bytes_per_rotation)
 
     keep = []

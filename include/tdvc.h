@@ -106,6 +106,16 @@ int tdvc_conv_fwd(const tdvc_conv_desc* d, const tdvc_conv_fwd_args* a, void* st
 int tdvc_conv_dgrad(const tdvc_conv_desc* d, const tdvc_conv_dgrad_args* a, void* stream);
 int tdvc_conv_wgrad(const tdvc_conv_desc* d, const tdvc_conv_wgrad_args* a, void* stream);
 size_t tdvc_conv_wgrad_workspace(const tdvc_conv_desc* d);
+/* Deferred weight-gradient folds. Every weight-grad entry point (tdvc_conv_wgrad, tdvc_film_cond0_bwd) ends with a fold of
+ * its per-block partial slabs (in `workspace`) into dw / dbias. With tdvc_fold_defer(1) that fold is queued on the stream
+ * instead of launched, and up to 24 queued folds run as ONE launch: when the queue is full, when a new fold targets a
+ * gradient that is already queued, or on tdvc_fold_flush(stream). The caller then owns two duties: every call gets a
+ * workspace region that stays untouched until the flush, and tdvc_fold_flush runs before anything reads dw / dbias or
+ * reuses a region. Default: off (each call folds before it returns its stream position). Process-wide switch; the queues
+ * are per stream. */
+void tdvc_fold_defer(int on);
+int tdvc_fold_flush(void* stream);
+
 /* TEST-ONLY process-global switches (see the conventions above).
  * tdvc_set_force_generic: route convs to the scalar (non-MFMA) kernels, to cross-check the two code paths.
  * tdvc_debug_force_tile: pin the tile configuration of the lean stride-1 conv kernel (cfg 0..6 = <M_REP,N_REP,WM,WN> of

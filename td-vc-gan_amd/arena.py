@@ -228,11 +228,13 @@ class ParamArena:
         """Called by the operators right after a weight-gradient launch of `slot`'s layer was queued."""
         self.queue_finish()
         if self._track is not None and slot.seg >= 0 and self._track.note(slot.seg):
+            self._flush_folds()
             self._segment_ready(slot.seg)
 
     def finish_grads(self):
         """Fold the effective-weight gradients into (v, g) gradients and expose .grad views."""
         self._finish_queued = False
+        self._flush_folds()
         if self._track is not None:
             for seg in self._track.finish():
                 self._segment_ready(seg)
@@ -244,6 +246,12 @@ class ParamArena:
                 o = self.offsets[k]
                 p.grad = self.G[o:o + p.numel()].view(p.shape)
             self._grads_attached = True
+
+    def _flush_folds(self):
+        """The weight-grad folds are deferred (ops.workspace): launch the queued ones before dW / G are read."""
+        if self.device.type == 'cuda':
+            from . import ops
+            ops.fold_flush(self.device)
 
     def queue_finish(self):
         """Called from inside a backward: run finish_grads once, when this backward pass ends."""

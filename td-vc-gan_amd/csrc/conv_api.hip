@@ -15,6 +15,8 @@ int wgrad_geometry(WgradP& p, int B, int* bpb_out);
 bool wgrad_mfma_supported(int J);
 hipError_t launch_slab_reduce(const float*, int, long, long, float*, int, long, hipStream_t, long n_w = -1, float* dbias = nullptr);
 hipError_t launch_bias_grad(const Opnd&, int, int, int, float*, hipStream_t);
+hipError_t fold_flush(hipStream_t st);
+void fold_set_defer(int on);
 }  // namespace tdvc
 
 namespace tdvc {
@@ -336,4 +338,12 @@ extern "C" int tdvc_film_cond_fwd(const tdvc_film_cond_args* a, void* stream) {
   hipError_t e = launch_conv_lean_cond(q, a->B, (hipStream_t)stream);
   if (e == hipErrorNotSupported) return tdvc_fail(TDVC_EUNSUPPORTED, "film_cond_fwd: shape outside the fused kernel's contract");
   return e == hipSuccess ? TDVC_OK : tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));
+}
+
+// Deferred weight-gradient folds (include/tdvc.h)
+extern "C" void tdvc_fold_defer(int on) { tdvc::fold_set_defer(on); }
+extern "C" int tdvc_fold_flush(void* stream) {
+  const hipError_t e = tdvc::fold_flush((hipStream_t)stream);
+  if (e != hipSuccess) return tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));
+  return TDVC_OK;
 }

@@ -744,6 +744,38 @@ __global__ __launch_bounds__(256) void slab_reduce_kernel(const float* slab, int
   }
 }
 
+// Several folds in one launch (deferred folds, tdvc_fold_defer): the folds of a backward pass are ~270 launches of ~4-16 us
+// each, mostly launch latency; batched, their blocks run side by side. A block finds its fold by its position in the
+// concatenated grids.
+struct FoldDesc {
+  const float* slab; float* dw; float* dbias;
+  long stride, n, dst_row_stride, n_w;
+  int nslab, rowlen, gx, gy, per_y, blk0;
+};
+constexpr int FOLD_MAX = 24;
+struct FoldBatch { FoldDesc d[FOLD_MAX]; int count, nblocks; };
+
+__global__ __launch_bounds__(256) void slab_reduce_multi_kernel(const FoldBatch fb) {
+  int k = 0;
+  for (int i = 1; i < fb.count; ++i)
+    if ((int)blockIdx.x >= fb.d[i].blk0) k = i;
+  const FoldDesc& f = fb.d[k];
+  const int lb = blockIdx.x - f.blk0, bx = lb % f.gx, by = lb / f.gx;
+  const int s0 = by * f.per_y, s1 = min(f.nslab, s0 + f.per_y);
+  for (long i = (long)bx * 256 + threadIdx.x; i < f.n; i += (long)f.gx * 256) {
+    float s = 0.f;
+    for (int q = s0; q < s1; ++q) s += f.slab[(long)q * f.stride + i];
+    float* dstp;
+    if (i >= f.n_w) dstp = f.dbias + (i - f.n_w);
+    else {
+      long dst = i;
+      if (f.dst_row_stride != f.rowlen) { const long r = i / f.rowlen; dst = r * f.dst_row_stride + (i - r * f.rowlen); }
+      dstp = f.dw + dst;
+    }
+    if (f.gy == 1) *dstp += s; else atomicAdd(dstp, s);
+  }
+}
+
 // Scalar weight-gradient: one block per weight element, reduction over (b, n).
 template <int MODE>
 __global__ __launch_bounds__(256) void conv_wgrad_scalar_kernel(const WgradP p, int B, float* dw) {
@@ -1006,6 +1038,27 @@ hipError_t launch_conv_wgrad_scalar(WgradP p, int B, long nweights, float* dw, h
 template hipError_t launch_conv_wgrad_scalar<MODE_DIRECT>(WgradP, int, long, float*, hipStream_t);
 template hipError_t launch_conv_wgrad_scalar<MODE_DOWN>(WgradP, int, long, float*, hipStream_t);
 
+// Deferred folds (tdvc_fold_defer(1)): launch_slab_reduce queues the fold on its stream instead of launching it; the queue
+// is flushed as ONE launch when it is full, when a queued fold already targets the same gradient (keeps the accumulation
+// order of a layer that is used twice in a backward pass), or by tdvc_fold_flush. The caller keeps the slabs intact until
+// the flush (td-vc-gan_amd/ops.py hands every weight-grad its own region of a ring and flushes on wrap) and flushes before
+// anything reads the gradients.
+static int g_fold_defer = 0;
+static std::mutex g_fold_mu;
+static std::map<hipStream_t, FoldBatch>& fold_pending() { static std::map<hipStream_t, FoldBatch> m; return m; }
+
+static hipError_t fold_flush_locked(hipStream_t st) {
+  auto it = fold_pending().find(st);
+  if (it == fold_pending().end() || it->second.count == 0) return hipSuccess;
+  FoldBatch& fb = it->second;
+  TDVC_TRACE(slab_reduce_multi_kernel);
+  hipLaunchKernelGGL(slab_reduce_multi_kernel, dim3(fb.nblocks), dim3(256), 0, st, fb);
+  fb.count = 0; fb.nblocks = 0;
+  return hipGetLastError();
+}
+hipError_t fold_flush(hipStream_t st) { std::lock_guard<std::mutex> lk(g_fold_mu); return fold_flush_locked(st); }
+void fold_set_defer(int on) { g_fold_defer = on ? 1 : 0; }
+
 hipError_t launch_slab_reduce(const float* slab, int nslab, long stride, long n, float* dw, int rowlen, long dst_row_stride,
                               hipStream_t st, long n_w = -1, float* dbias = nullptr) {
   if (n_w < 0) n_w = n;
@@ -1014,6 +1067,19 @@ hipError_t launch_slab_reduce(const float* slab, int nslab, long stride, long n,
   if (nslab > 8) { gy = 1024 / gx; if (gy > (nslab + 7) / 8) gy = (nslab + 7) / 8; if (gy < 1) gy = 1; }
   const int per_y = (nslab + gy - 1) / gy;
   gy = (nslab + per_y - 1) / per_y;
+  if (g_fold_defer) {
+    std::lock_guard<std::mutex> lk(g_fold_mu);
+    FoldBatch& fb = fold_pending()[st];
+    bool clash = fb.count == FOLD_MAX;
+    for (int i = 0; i < fb.count && !clash; ++i)
+      clash = fb.d[i].dw == dw || (dbias && fb.d[i].dbias == dbias);
+    if (clash) { const hipError_t e = fold_flush_locked(st); if (e != hipSuccess) return e; }
+    FoldDesc& f = fb.d[fb.count++];
+    f.slab = slab; f.dw = dw; f.dbias = dbias; f.stride = stride; f.n = n; f.dst_row_stride = dst_row_stride; f.n_w = n_w;
+    f.nslab = nslab; f.rowlen = rowlen; f.gx = gx; f.gy = gy; f.per_y = per_y; f.blk0 = fb.nblocks;
+    fb.nblocks += gx * gy;
+    return hipSuccess;
+  }
   TDVC_TRACE(slab_reduce_kernel);
   hipLaunchKernelGGL(slab_reduce_kernel, dim3(gx, gy), dim3(256), 0, st, slab, nslab, stride, n, dw, rowlen, dst_row_stride, per_y, n_w, dbias);
   return hipGetLastError();

@@ -48,18 +48,45 @@ class ConvSpec:
 
 
 # ------------------------------------------------------------------------------- workspace
+# Weight-gradient kernels leave per-block partial slabs in a workspace and fold them into dW. The folds are DEFERRED
+# (include/tdvc.h: tdvc_fold_defer): the library queues them and runs up to 24 as one launch, which takes ~250 launches
+# of mostly launch latency out of a backward pass. The duties that come with it live here: every weight-grad call gets
+# its own region of a ring buffer (the slabs must survive until the flush), the ring flushes before it wraps, and
+# fold_flush() runs before anything reads the gradients (ParamArena.finish_grads / segment hand-over, tests).
+FOLD_DEFER = os.environ.get('TDVC_FOLD_DEFER', '1') == '1'
+RING_BYTES = int(os.environ.get('TDVC_FOLD_RING_MB', '1024')) << 20
 _ws = {}
 
 
+def fold_flush(device):
+    """Launch the queued folds of `device`'s current stream (no-op when nothing is queued)."""
+    if FOLD_DEFER:
+        L.check(L.lib().tdvc_fold_flush(torch.cuda.current_stream(device).cuda_stream))
+
+
 def workspace(device, nbytes):
-    """Grow-only scratch buffer for wgrad slabs (sized during eager warm-up, stable under graph capture)."""
-    buf = _ws.get(device)
-    if buf is None or buf.numel() < nbytes:
+    """A region of `nbytes` for the slabs of one weight-grad call -> (buffer, byte offset). Grow-only outside graph
+    capture (the eager warm-up step sizes it)."""
+    ent = _ws.get(device)
+    need = max(nbytes, 1 << 20)
+    if ent is None or ent[0].numel() < need:
         if torch.cuda.is_current_stream_capturing():
             raise L.TdvcError('wgrad workspace would have to grow during graph capture: run an eager step first')
-        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
-        _ws[device] = buf
-    return buf
+        if ent is not None:
+            fold_flush(device)
+            torch.cuda.current_stream(device).synchronize()
+        L.lib().tdvc_fold_defer(1 if FOLD_DEFER else 0)
+        size = max(need * 2, RING_BYTES) if FOLD_DEFER else need
+        ent = [torch.empty(size, dtype=torch.uint8, device=device), 0]
+        _ws[device] = ent
+    if not FOLD_DEFER:
+        return ent[0], 0
+    off = ent[1]
+    if off + nbytes > ent[0].numel():            # wrap: the queued folds still read the old regions
+        fold_flush(device)
+        off = 0
+    ent[1] = (off + nbytes + 255) & ~255
+    return ent[0], off
 
 
 def _xf(kind=L.XF_NONE, slope=SLOPE, scale=1.0, aux=None):
@@ -118,12 +145,14 @@ def conv_wgrad_raw(spec: ConvSpec, x, x_xf, dy, dy_xf):
     d = spec.desc(B, tin)
     lib = L.lib()
     nbytes = lib.tdvc_conv_wgrad_workspace(C.byref(d))
-    ws = workspace(x.device, nbytes) if nbytes else None
+    ws, off = workspace(x.device, nbytes) if nbytes else (None, 0)
     a = L.ConvWgradArgs(x.data_ptr(), _bs(x), x_xf, dy.data_ptr(), _bs(dy), dy_xf, s.dw, s.db or None,
-                        ws.data_ptr() if ws is not None else None, ws.numel() if ws is not None else 0)
+                        ws.data_ptr() + off if ws is not None else None, nbytes if ws is not None else 0)
     L.check(lib.tdvc_conv_wgrad(C.byref(d), C.byref(a), _stream(x)))
     if s.arena is not None:
         s.arena.note_grad(s)
+    else:
+        fold_flush(x.device)            # stand-alone use (tests, tools): the caller reads dw right away
 
 
 PRE_NONE, PRE_LRELU = 0, 1
@@ -279,14 +308,16 @@ class FilmCondFn(Function):
         dexc = torch.empty_like(exc) if ctx.needs_input_grad[0] else None
         dk3 = torch.empty((B, nc, 3), dtype=torch.float32, device=dgb.device)
         nbytes = lib.tdvc_film_cond0_bwd_workspace(B, T, nc, nv) if want_w else 0
-        ws = workspace(dgb.device, nbytes) if nbytes else None
+        ws, off = workspace(dgb.device, nbytes) if nbytes else (None, 0)
         a = L.FilmCond0BwdArgs(B, T, nc, nv, dcv.data_ptr(), _bs(dcv), exc.data_ptr(), _bs(exc), sv.w,
                                dexc.data_ptr() if dexc is not None else None, _bs(dexc) if dexc is not None else 0,
                                dk3.data_ptr(), sv.dw if want_w else None,
-                               ws.data_ptr() if ws is not None else None, ws.numel() * ws.element_size() if ws is not None else 0)
+                               ws.data_ptr() + off if ws is not None else None, nbytes if ws is not None else 0)
         L.check(lib.tdvc_film_cond0_bwd(C.byref(a), _stream(dgb)))
         if want_w and sv.arena is not None:
             sv.arena.note_grad(sv)
+        elif want_w:
+            fold_flush(dgb.device)
         return dexc, dk3, None, None, None
 
 
