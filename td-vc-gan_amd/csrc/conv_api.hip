@@ -4,6 +4,7 @@
 #include "conv_common.h"
 #include "conv_lean.h"
 #include "conv_wgrad_lean.h"
+#include "conv_small_group.h"
 #include "api_util.h"
 
 namespace tdvc {
@@ -82,6 +83,16 @@ static int check_desc(const tdvc_conv_desc* d) {
 
 static inline int ceil_div(int a, int b) { return (a + b - 1) / b; }
 
+// Grouped strided conv with 4 -> 4 channels per group (discriminator layer 4): vector-ALU kernels of conv_small_group.hip
+static bool small_group_ok(const tdvc_conv_desc* d) {
+  return !g_force_generic && g_knob[2] == 0 && d->kind == TDVC_CONV && d->groups >= 16 && d->Cin == 4 * d->groups && d->Cout == 4 * d->groups &&
+         d->dilation == 1 && !d->reflect && d->w_cin == 0 && d->stride >= 2 && d->stride <= 8 && d->K <= 48;
+}
+static void small_group_base(const tdvc_conv_desc* d, SmallGroupP& q) {
+  q.B = d->B; q.G = d->groups; q.Tin = d->Tin; q.Tout = d->Tout; q.K = d->K; q.s = d->stride; q.pad = d->pad;
+  q.in_scale = 1.f; q.out_scale = 1.f; q.dy_scale = 1.f;
+}
+
 static bool use_mfma(const GemmConvP& p) {
   if (g_force_generic) return false;
   if (p.R <= 2 && p.x.Cg == 1 && p.Cy_g <= 2) return false;   // depthwise / single-channel FIR filters
@@ -106,6 +117,16 @@ extern "C" int tdvc_conv_fwd(const tdvc_conv_desc* d, const tdvc_conv_fwd_args* 
   if (int rc = check_desc(d)) return rc;
   if (!a || !a->x || !a->w || !a->y) return tdvc_fail(TDVC_EINVAL, "conv_fwd: null pointer");
   const int Cin_g = d->Cin / d->groups, Cout_g = d->Cout / d->groups;
+  if (small_group_ok(d) && a->x_xf.kind <= TDVC_XF_LRELU && !a->res && !a->add && !a->bias3) {
+    SmallGroupP q = {};
+    small_group_base(d, q);
+    q.x = a->x; q.x_bs = a->x_bs; q.w = a->w; q.bias = a->bias; q.y = a->y; q.y_bs = a->y_bs;
+    q.act_in = a->x_xf.kind == TDVC_XF_LRELU; q.slope_in = a->x_xf.slope; q.in_scale = a->x_xf.scale == 0.f ? 1.f : a->x_xf.scale;
+    q.post = a->post_act; q.post_slope = a->post_slope; q.out_scale = a->out_scale == 0.f ? 1.f : a->out_scale;
+    const hipError_t e = launch_small_group_fwd(q, (hipStream_t)stream);
+    if (e == hipSuccess) return TDVC_OK;
+    if (e != hipErrorNotSupported) return tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));
+  }
   if (!g_force_generic && lean_shape_ok(d) && (d->Cin & 3) == 0) {
     LeanP q = {};
     float slope, scale; const float* aux; long aux_bs;
@@ -154,6 +175,17 @@ extern "C" int tdvc_conv_dgrad(const tdvc_conv_desc* d, const tdvc_conv_dgrad_ar
   if (int rc = check_desc(d)) return rc;
   if (!a || !a->dy || !a->w || !a->dx) return tdvc_fail(TDVC_EINVAL, "conv_dgrad: null pointer");
   const int Cin_g = d->Cin / d->groups, Cout_g = d->Cout / d->groups;
+  if (small_group_ok(d) && a->epilogue == TDVC_DG_PLAIN && !a->add &&
+      (a->dy_xf.kind == TDVC_XF_NONE || (a->dy_xf.kind == TDVC_XF_MASK_LRELU && a->dy_xf.aux))) {
+    SmallGroupP q = {};
+    small_group_base(d, q);
+    q.dy = a->dy; q.dy_bs = a->dy_bs; q.w = a->w; q.y = a->dx; q.y_bs = a->dx_bs;
+    q.dy_scale = a->dy_xf.scale == 0.f ? 1.f : a->dy_xf.scale;
+    if (a->dy_xf.kind == TDVC_XF_MASK_LRELU) { q.mask = a->dy_xf.aux; q.mask_bs = a->dy_xf.aux_bs; q.m_slope = a->dy_xf.slope; }
+    const hipError_t e = launch_small_group_dgrad(q, (hipStream_t)stream);
+    if (e == hipSuccess) return TDVC_OK;
+    if (e != hipErrorNotSupported) return tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));
+  }
   if (!g_force_generic && a->wt && lean_shape_ok(d) && (d->Cout & 3) == 0 && (d->K - 1) * d->dilation - d->pad >= 0) {
     LeanP q = {};
     float slope, scale; const float* aux; long aux_bs;
@@ -251,16 +283,18 @@ namespace tdvc { int wgrad_lean_nslab(int R, int Cin, int N, int K, int B); }
 
 extern "C" size_t tdvc_conv_wgrad_workspace(const tdvc_conv_desc* d) {
   if (check_desc(d)) return 0;
+  size_t small = small_group_ok(d) ? small_group_wgrad_workspace(d->B, d->groups, d->K) : 0;
   if (wgrad_lean_ok(d)) {
     return (size_t)wgrad_lean_nslab(d->Cout, d->Cin, d->Tout, d->K, d->B) * ((size_t)d->Cout * d->Cin * d->K + d->Cout) * sizeof(float);
   }
   WgradP p = {};
   fill_wgrad(d, nullptr, p);
-  if (!wgrad_use_mfma(p)) return 0;
+  if (!wgrad_use_mfma(p)) return small;
   int bpb;
   const int nslab = wgrad_geometry(p, d->B, &bpb);
   const long wsize = (long)d->groups * p.w_sg;
-  return (size_t)nslab * (size_t)wsize * sizeof(float);
+  const size_t gen = (size_t)nslab * (size_t)wsize * sizeof(float);
+  return gen > small ? gen : small;
 }
 
 extern "C" int tdvc_conv_wgrad(const tdvc_conv_desc* d, const tdvc_conv_wgrad_args* a, void* stream) {
@@ -272,6 +306,19 @@ extern "C" int tdvc_conv_wgrad(const tdvc_conv_desc* d, const tdvc_conv_wgrad_ar
   const long wsize = (long)d->groups * p.w_sg;
   hipError_t e = hipSuccess;
   bool done = false, bias_done = false;
+  if (a->dw && small_group_ok(d) && a->x_xf.kind <= TDVC_XF_LRELU &&
+      (a->dy_xf.kind == TDVC_XF_NONE || (a->dy_xf.kind == TDVC_XF_MASK_LRELU && a->dy_xf.aux))) {
+    SmallGroupP q = {};
+    small_group_base(d, q);
+    q.x = a->x; q.x_bs = a->x_bs; q.dy = a->dy; q.dy_bs = a->dy_bs;
+    q.act_in = a->x_xf.kind == TDVC_XF_LRELU; q.slope_in = a->x_xf.slope; q.in_scale = a->x_xf.scale == 0.f ? 1.f : a->x_xf.scale;
+    q.dy_scale = a->dy_xf.scale == 0.f ? 1.f : a->dy_xf.scale;
+    if (a->dy_xf.kind == TDVC_XF_MASK_LRELU) { q.mask = a->dy_xf.aux; q.mask_bs = a->dy_xf.aux_bs; q.m_slope = a->dy_xf.slope; }
+    e = launch_small_group_wgrad(q, a->dw, a->dbias, a->workspace, a->workspace_bytes, st);
+    if (e == hipSuccess) return TDVC_OK;
+    if (e != hipErrorNotSupported) return tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));
+    e = hipSuccess;
+  }
   if (a->dw && wgrad_lean_ok(d)) {
     WgLeanP q = {};
     q.a = p.a; q.x = p.x; q.R = d->Cout; q.Cin = d->Cin; q.N = d->Tout; q.pad = d->pad; q.K = d->K; q.reflect = d->reflect;
