@@ -36,7 +36,9 @@ struct Cond0BwdP {
 
 constexpr int CB_NT = 64;              // time steps per chunk
 constexpr int CB_NV = 18;              // float4 columns staged: aligned window [n0 - 4, n0 + 68)
-constexpr int CB_S = 74;               // LDS row stride of the tiles, 2 (mod 4)
+constexpr int CB_S = 76;               // LDS row stride of the tiles: 12 (mod 64) -> the 16 rows x 4 columns of a (b) fragment read hit 64 distinct
+                                       // banks (16 distinct multiples of 4, + kq), rows are 16-byte aligned
+constexpr int CB_G = 36;               // (a): lane group kq reduces channels kq*36 + cs; 36 * 76 = 48 (mod 64) -> the 4 groups' 16-column reads are disjoint
 constexpr int CB_WS = 26;              // staged weight row: 24 taps + 2 zeros
 constexpr int CB_CT = 9;               // channel tiles of 16: nc <= 144
 constexpr int CB_ROWS = CB_CT * 16;
@@ -108,8 +110,7 @@ __global__ __launch_bounds__(256, 2) void film_cond0_bwd_kernel(const Cond0BwdP 
 #pragma unroll
       for (int i = 0; i < CB_NP; ++i) {
         if (i * CB_RP + rsub < CB_ROWS) {
-          f32x2* d = reinterpret_cast<f32x2*>(ds + lds_off + i * CB_RP * CB_S);
-          d[0] = (f32x2){v[i][0], v[i][1]}; d[1] = (f32x2){v[i][2], v[i][3]};
+          *reinterpret_cast<f32x4*>(ds + lds_off + i * CB_RP * CB_S) = v[i];
         }
       }
     }
@@ -144,13 +145,13 @@ __global__ __launch_bounds__(256, 2) void film_cond0_bwd_kernel(const Cond0BwdP 
     // ---- (a) dexc tile: rows t = 16 * wave + ln, reduction over (channel group, tap)
     if (p.dexc) {
       f32x4 acc1[3] = {{0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}, {0.f, 0.f, 0.f, 0.f}};   // one chain per tap
-      const float* ap = ds + kq * CB_S + wave * 16 + ln + 4 + 1;      // d_cv0[c = 4 cs + kq][t + 1 - j]
-      const float* wp = wsm + kq * CB_WS + wcol;                       // W0x[c = 4 cs + kq][ce = ln][j]
-      const int ngrp = p.nc >> 2;
-      for (int cs = 0; cs < ngrp; ++cs) {
+      // the k index of a step is free: lane group kq takes channel kq * CB_G + cs (rows >= nc are zero in both operands)
+      const float* ap = ds + kq * CB_G * CB_S + wave * 16 + ln + 4 + 1;      // d_cv0[c = 36 kq + cs][t + 1 - j]
+      const float* wp = wsm + kq * CB_G * CB_WS + wcol;                       // W0x[c = 36 kq + cs][ce = ln][j]
+      for (int cs = 0; cs < CB_G; ++cs) {
 #pragma unroll
         for (int j = 0; j < 3; ++j)
-          acc1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[cs * 4 * CB_S - j], wp[cs * 4 * CB_WS + (ln < 8 ? j : 0)], acc1[j], 0, 0, 0);
+          acc1[j] = __builtin_amdgcn_mfma_f32_16x16x4f32(ap[cs * CB_S - j], wp[cs * CB_WS + (ln < 8 ? j : 0)], acc1[j], 0, 0, 0);
       }
       const f32x4 d1 = acc1[0] + acc1[1] + acc1[2];
       const int t0 = n0 + wave * 16 + kq * 4;        // D1[t = 16w + 4 kq + r][ce = ln]
