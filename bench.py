@@ -34,7 +34,9 @@ def parse_args():
     ap.add_argument('--steps', type=int, default=20)
     ap.add_argument('--warmup', type=int, default=5)
     ap.add_argument('--batch', type=int, default=16, help='samples per GPU (1 s each)')
-    ap.add_argument('--config', default='conv_enc-stage1')
+    ap.add_argument('--seconds', type=float, default=1.0, help='length of each sample in seconds (BASELINE config #5: 2)')
+    ap.add_argument('--config', default='conv_enc-stage1', help='conv_enc-stage1 | conv_enc-stage2_1 | conv_enc-stage2_2 | wavlm-stage2_2 (frozen SSL '
+                                                                "extractor = synth.FrameFeatureExtractor, the stand-in for WavLM-Large whose checkpoint is absent)")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-table', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='run eagerly instead of replaying a captured hipGraph')
@@ -261,7 +263,7 @@ def cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(pkg, cfg_train, iters=3):
+def cpu_baseline(pkg, cfg_train, iters=3, sd_g=None, ssl=False):
     """CPU oracle timed on this host: B=2 x 1 s, 1 warm-up + `iters` timed iterations (~10-30 s)."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -270,7 +272,7 @@ def cpu_baseline(pkg, cfg_train, iters=3):
     cores = usable_cores()
     torch.set_num_threads(cores)
     cfg = OS.StepConfig.from_hparams(cfg_train)
-    st = OS.TrainStep(filled_sd('G'), filled_sd('D'), cfg)
+    st = OS.TrainStep(sd_g if sd_g is not None else filled_sd('G'), filled_sd('D'), cfg, ssl_extractor=pkg.synth.FrameFeatureExtractor() if ssl else None)
     B, T = 2, SR
     bt = pkg.synth.make_batch(B, T, seed=1234, conversion=not cfg.no_conv)
     ix, iy = pkg.synth.contrastive_indices(B, T // 320, cfg.n_neg, 1), pkg.synth.contrastive_indices(B, T // 320, cfg.n_neg, 2)
@@ -322,18 +324,25 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
 
     pkg = importlib.import_module('td-vc-gan_amd')
-    from common import build_models, to_dev
+    from common import build_models, build_ssl_models, to_dev
     import warnings
     hp = pkg.hparams.HParam(os.path.join(ROOT, 'config', f'{args.config}.yaml'))
     with warnings.catch_warnings():
         warnings.simplefilter('ignore')      # lambda_f0: the CREPE-backed term is excluded by contract (named in config.workload)
         cfg = pkg.train_step.StepConfig.from_hparams(hp.train)
-    G, D = build_models(dev)
+    ssl = args.config.startswith('wavlm')
+    sd_g = None
+    if ssl:
+        G, D, sd_g = build_ssl_models(dev)
+    else:
+        G, D = build_models(dev)
     sync = pkg.parallel.GradSync() if dp else None
     if sync is not None:
         sync.broadcast_params(G.arena); sync.broadcast_params(D.arena)
     ts = pkg.train_step.TrainStep(G, D, cfg, dev, grad_sync=sync)
-    B, T = args.batch, SR
+    B, T = args.batch, int(round(SR * args.seconds))
+    if T % 320:
+        raise SystemExit('--seconds must give a multiple of 320 samples (the content encoder hop)')
     bt = to_dev(pkg.synth.make_batch(B, T, seed=1234 + rank, conversion=not cfg.no_conv), dev)
     ix = pkg.synth.contrastive_indices(B, T // 320, cfg.n_neg, 17 + rank).to(dev)
     iy = pkg.synth.contrastive_indices(B, T // 320, cfg.n_neg, 917 + rank).to(dev)
@@ -385,8 +394,10 @@ def main():
         out = dict(metric=f'audio-seconds/sec (G+D train step, {stage})', value=value, unit='audio-seconds/sec', n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=step_ms, higher_is_better=True,
                    scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
-                   config=dict(workload=f'config/{args.config}.yaml full D+G iteration, {B} x 1 s @16 kHz per GPU, NUM_SPK=16, '
-                                        'F0 (CREPE) loss term excluded', global_batch=world * B, parallelism=f'dp{world}'),
+                   config=dict(workload=f'config/{args.config}.yaml full D+G iteration, {B} x {args.seconds:g} s @16 kHz per GPU, NUM_SPK=16, '
+                                        'F0 (CREPE) loss term excluded' + (', frozen SSL extractor = synthetic stand-in for WavLM-Large '
+                                                                           '(plain PyTorch, inside the timed step)' if ssl else ''),
+                               global_batch=world * B, parallelism=f'dp{world}'),
                    final_G_loss=g_loss, launch=launch)
         if world == 1 and not args.no_kernel_table and 'stage1' in args.config:      # rank 0 of a multi-rank run goes straight to the JSON line
             table, north = kernel_table(pkg, dev, B, step_ms)
@@ -404,7 +415,7 @@ def main():
             roof['table_share_of_step'] = sum(e['share_of_step'] for e in table)
             out['roofline'] = roof
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(pkg, hp.train)
+            out['cpu_baseline'] = cpu_baseline(pkg, hp.train, sd_g=sd_g, ssl=ssl)
             out['speedup_vs_cpu'] = value / out['cpu_baseline']['value']
         print(json.dumps(out), flush=True)
     if dp:

@@ -75,7 +75,11 @@ class AdamW:
 
 
 class TrainStep:
-    def __init__(self, sd_g: dict, sd_d: dict, cfg: StepConfig, sd_c: dict = None):
+    def __init__(self, sd_g: dict, sd_d: dict, cfg: StepConfig, sd_c: dict = None, ssl_extractor=None):
+        """ssl_extractor: for a generator with encoder_model='wavlm' (model/generator.py:453-454) the frozen feature
+        extractor `wave [B, L] -> [B, L', 1024]` features (model/ssl_encoder.py:141-145: 160-sample left pad, no grad);
+        None = the conv content encoder."""
+        self.ssl = ssl_extractor
         self.g = {k: v.clone().requires_grad_(True) for k, v in sd_g.items()}
         self.d = {k: v.clone().requires_grad_(True) for k, v in sd_d.items()}
         self.cfg = cfg
@@ -89,10 +93,26 @@ class TrainStep:
             self.c = {k: v.clone().requires_grad_(True) for k, v in sd_c.items()}
             self.opt_c = AdamW(self.c, cfg.lr_d, cfg.betas, cfg.eps, 0.0)
 
+    # -- generator / content encoder, conv or SSL-conditioned ------------------------
+    def _ssl_features(self, x):
+        with torch.no_grad():      # model/ssl_encoder.py:141-145
+            c = self.ssl.extract_features(torch.nn.functional.pad(x, (160, 0)).squeeze(1))[0]
+        return c.transpose(1, 2)
+
+    def _generator(self, x, c, c_var):
+        if self.ssl is None:
+            return M.generator(self.g, x, c, c_var)
+        return M.generator_ssl(self.g, self._ssl_features(x), c, c_var)
+
+    def _encoder(self, x):
+        if self.ssl is None:
+            return M.encoder(self.g, x)
+        return M.ssl_content_encoder(self.g, self._ssl_features(x))
+
     # -- D-step ---------------------------------------------------------------------
     def d_losses(self, batch):
         with torch.no_grad():  # G is not updated by the D-step (Q3)
-            fake, fake_subs, _ = M.generator(self.g, batch['signal_real'], batch['c_tgt'], batch['c_f0_conv'])
+            fake, fake_subs, _ = self._generator(batch['signal_real'], batch['c_tgt'], batch['c_f0_conv'])
         real_subs = M.disc_subsamples(batch['signal_real'])
         out_real, _ = M.discriminator(self.d, batch['signal_real'], batch['label_src'], real_subs)
         out_fake, _ = M.discriminator(self.d, fake, batch['label_tgt'], fake_subs)
@@ -103,7 +123,7 @@ class TrainStep:
     def g_losses(self, batch, idx_x, idx_y):
         c = self.cfg
         x = batch['signal_real']
-        fake, fake_subs, emb_real = M.generator(self.g, x, batch['c_tgt'], batch['c_f0_conv'])
+        fake, fake_subs, emb_real = self._generator(x, batch['c_tgt'], batch['c_f0_conv'])
         out_fake, feats_fake = M.discriminator(self.d, fake, batch['label_tgt'], fake_subs)
         adv = L.lsgan_to_one(out_fake)
         out = dict(G_loss_adv_fake=adv)
@@ -114,7 +134,7 @@ class TrainStep:
                 _, feats_real = M.discriminator(self.d, x, batch['label_src'], M.disc_subsamples(x))
         if not c.no_conv and c.lambda_rec > 0:
             # cycle reconstruction (train.py:344-361): the converted signal, detached, converted back to the source speaker
-            rec, rec_subs, _ = M.generator(self.g, fake.detach(), batch['c_src'], batch['c_f0_src'])
+            rec, rec_subs, _ = self._generator(fake.detach(), batch['c_src'], batch['c_f0_src'])
             rec_loss = 0
             if c.lambda_feat > 0:
                 _, feats_rec = M.discriminator(self.d, rec, batch['label_src'], rec_subs)
@@ -129,7 +149,7 @@ class TrainStep:
             if c.no_conv:
                 idt, idt_subs, feats_idt_src = fake, fake_subs, None
             else:
-                idt, idt_subs, _ = M.generator(self.g, x, batch['c_src'], batch['c_f0_src'])
+                idt, idt_subs, _ = self._generator(x, batch['c_src'], batch['c_f0_src'])
             idt_loss = 0
             if c.lambda_feat > 0:
                 _, feats_idt = M.discriminator(self.d, idt, batch['label_src'], idt_subs)
@@ -144,7 +164,7 @@ class TrainStep:
             out['G_loss_lat_cls'] = torch.nn.functional.cross_entropy(M.latent_classifier(self.c, emb_real), batch['label_src'])
             total = total + c.lambda_latcls * out['G_loss_lat_cls']
         if c.lambda_cont_emb > 0 and c.lambda_corrupted:
-            emb_cor = M.encoder(self.g, batch['signal_corrupted'])
+            emb_cor = self._encoder(batch['signal_corrupted'])
             out['G_loss_cont_emb'] = L.contrastive(emb_real, emb_cor, idx_x, idx_y)
             total = total + c.lambda_cont_emb * out['G_loss_cont_emb']
         out['G_loss'] = total
@@ -160,7 +180,7 @@ class TrainStep:
         cl = {}
         if self.c is not None:      # latent-classifier step (train.py:300-308) on the detached content embedding:
             with torch.no_grad():   # its gradient into G is dead work (G is not stepped here, grads are zeroed before the G-step)
-                emb = M.encoder(self.g, batch['signal_real'])
+                emb = self._encoder(batch['signal_real'])
             self.opt_c.zero_grad()
             logits = M.latent_classifier(self.c, emb)
             cl['C_loss'] = torch.nn.functional.cross_entropy(logits, batch['label_src'])

@@ -173,3 +173,24 @@ def contrastive_indices(B: int, T: int, n_neg: int, seed: int) -> torch.Tensor:
     """
     rs = np.random.RandomState(seed)
     return torch.from_numpy(rs.randint(0, T - 1, size=(B, T, n_neg)).astype(np.int64))
+
+
+class FrameFeatureExtractor(torch.nn.Module):
+    """Synthetic stand-in for the frozen SSL feature extractor of `encoder_model='wavlm'` (WavLM-Large: third-party, its
+    checkpoint wavlm/WavLM-Large.pt does not ship with the reference). Same interface and framing as the module the
+    reference calls (model/ssl_encoder.py:141-145): `extract_features(wave [B, L]) -> ([B, L', 1024], ...)` with a
+    receptive field of 400 samples and a hop of 320, i.e. L' = (L - 400) // 320 + 1 -- one frame per 320 samples of the
+    160-sample left-padded signal. Plain PyTorch (like the real extractor, it is not part of the HIP path); deterministic
+    weights, frozen. Used by the tests / tools on both the product and the oracle side."""
+
+    def __init__(self, dim: int = 1024, field: int = 400, hop: int = 320):
+        super().__init__()
+        rs = _rs('ssl_stand_in')
+        w = rs.uniform(-1.0, 1.0, size=(dim, 1, field)).astype(np.float32) * (4.0 / math.sqrt(field))
+        self.weight = torch.nn.Parameter(torch.from_numpy(w), requires_grad=False)
+        self.hop = hop
+
+    def extract_features(self, wave: torch.Tensor):
+        # gain: the training signals sit at -30 dB RMS; bring the frames to O(1) before the squashing non-linearity
+        f = torch.tanh(torch.nn.functional.conv1d(wave[:, None, :].float() * 30.0, self.weight, stride=self.hop))
+        return (f.transpose(1, 2).contiguous(),)

@@ -37,6 +37,24 @@ def build_models(dev):
     return G, D
 
 
+def build_ssl_models(dev):
+    """Generator(encoder_model='wavlm') with the stand-in frozen extractor + the shipped discriminator; returns the
+    state_dict of everything but the extractor (deterministic fill, like build_models)."""
+    P = pkg()
+    G = P.modules.Generator(**{**G_ARGS, 'encoder_model': 'wavlm', 'decoder_channels': list(G_ARGS['decoder_channels']),
+                               'cmodel': P.synth.FrameFeatureExtractor()})
+    D = P.modules.CollaborativeMultibandDiscriminator(**D_ARGS)
+    enc_shapes = json.load(open(os.path.join(GOLDEN, 'shapes_SSLENC.json')))
+    sd = {k: v for k, v in filled_sd('G').items() if not k.startswith('encoder.')}
+    sd.update({'encoder.encoder.' + k: v for k, v in P.synth.fill_state_dict(enc_shapes).items()})
+    res = G.load_state_dict(sd, strict=False)
+    assert not res.unexpected_keys and all(k.startswith('encoder.cmodel.') for k in res.missing_keys), res
+    D.load_state_dict(filled_sd('D'))
+    G.to(dev)
+    G.ensure_arena(dev); D.ensure_arena(dev)
+    return G, D, sd
+
+
 def to_dev(batch, dev):
     return {k: v.to(dev) for k, v in batch.items()}
 

@@ -4,6 +4,10 @@ had only run as B=2 fixtures, whose tile selection differs from the benchmark's)
   #2  config/conv_enc-stage1.yaml,   16 x 1 s  (the benchmark's launch shape: every kernel instance bench.py times)
   #3  config/conv_enc-stage2_1.yaml, 32 x 1 s  (no_conv reconstruction objective)
   #5' config/conv_enc-stage2_2.yaml,  4 x 1 s  (lambda_rec cycle branch, train.py:344-361; the conv-encoder twin of wavlm-stage2_2)
+  #5  config/wavlm-stage2_2.yaml,     8 x 2 s  (SSL-conditioned generator: 16-layer gated WN encoder on 1024-dim features + the
+      cycle branch, whose second generator pass re-extracts features from the converted signal). WavLM-Large itself is third-party
+      and its checkpoint is absent: the frozen extractor is synth.FrameFeatureExtractor (same interface / framing, plain PyTorch)
+      on both sides.
 
 For each: every logged loss scalar (1e-3), per-tensor rel-L2 of EVERY discriminator gradient (D-step) and EVERY
 generator gradient (G-step) against the oracle's autograd, and the parameter UPDATE p_after - p_before of both AdamW
@@ -15,7 +19,7 @@ import numpy as np
 import pytest
 import torch
 
-from common import GOLDEN, assert_grads_close, build_models, filled_sd, pkg, rel_l2, to_dev, traced
+from common import GOLDEN, assert_grads_close, build_models, build_ssl_models, filled_sd, pkg, rel_l2, to_dev, traced
 
 pytestmark = pytest.mark.gpu
 TOL = 1e-3
@@ -34,14 +38,14 @@ def update_stats(before, after_got, after_ref, lr):
     return float(flipped.double().mean()), rel_rest, float(d_ref.norm())
 
 
-CASES = [('conv_enc-stage1', 16), ('conv_enc-stage2_1', 32), ('conv_enc-stage2_2', 4)]
+CASES = [('conv_enc-stage1', 16, 16000), ('conv_enc-stage2_1', 32, 16000), ('conv_enc-stage2_2', 4, 16000), ('wavlm-stage2_2', 8, 32000)]
 
 
-@pytest.mark.parametrize('cfg_name,B', CASES, ids=[f'{c}_B{b}_T16000' for c, b in CASES])
-def test_full_iteration_vs_oracle(cfg_name, B, dev):
+@pytest.mark.parametrize('cfg_name,B,T', CASES, ids=[f'{c}_B{b}_T{t}' for c, b, t in CASES])
+def test_full_iteration_vs_oracle(cfg_name, B, T, dev):
     from oracle import step as OS
     P = pkg()
-    T = 16000
+    ssl = cfg_name.startswith('wavlm')
     hp = P.hparams.HParam(os.path.join(os.path.dirname(GOLDEN), '..', 'config', f'{cfg_name}.yaml'))
     import warnings
     with warnings.catch_warnings():
@@ -49,14 +53,18 @@ def test_full_iteration_vs_oracle(cfg_name, B, dev):
         cfg = P.train_step.StepConfig.from_hparams(hp.train)
     ocfg = OS.StepConfig.from_hparams(hp.train)
     torch.set_num_threads(max(1, min(32, len(os.sched_getaffinity(0)))))
-    G, D = build_models(dev)
+    if ssl:
+        G, D, sd_g = build_ssl_models(dev)
+    else:
+        G, D = build_models(dev)
+        sd_g = filled_sd('G')
     ts = P.train_step.TrainStep(G, D, cfg, dev)
     bt_cpu = P.synth.make_batch(B, T, seed=4242, conversion=not cfg.no_conv)
     bt = to_dev(bt_cpu, dev)
     ix = P.synth.contrastive_indices(B, T // 320, cfg.n_neg, seed=7)
     iy = P.synth.contrastive_indices(B, T // 320, cfg.n_neg, seed=8)
-    sd_g, sd_d = filled_sd('G'), filled_sd('D')
-    ost = OS.TrainStep(sd_g, sd_d, ocfg)
+    sd_d = filled_sd('D')
+    ost = OS.TrainStep(sd_g, sd_d, ocfg, ssl_extractor=P.synth.FrameFeatureExtractor() if ssl else None)
 
     # ---------------- D-step: forward + backward, gradients, update
     log = {}
@@ -93,6 +101,9 @@ def test_full_iteration_vs_oracle(cfg_name, B, dev):
     assert not bad, bad
     errs = {}
     for k, p in G.named_parameters():
+        if k.startswith('encoder.cmodel.'):        # frozen extractor: outside the optimizer on both sides
+            assert p.grad is None, k
+            continue
         og = ost.g[k].grad
         if og is None:
             assert p.grad is None or float(p.grad.abs().max()) == 0.0, f'{k}: oracle leaves grad None (Q7)'
@@ -103,7 +114,11 @@ def test_full_iteration_vs_oracle(cfg_name, B, dev):
     ts._g_update()
     ost.opt_g.step()
     torch.cuda.synchronize()
-    st_g = {k: update_stats(sd_g[k], p.detach(), ost.g[k].detach(), cfg.lr_g) for k, p in G.named_parameters() if ost.g[k].grad is not None}
+    st_g = {k: update_stats(sd_g[k], p.detach(), ost.g[k].detach(), cfg.lr_g) for k, p in G.named_parameters()
+            if k in ost.g and ost.g[k].grad is not None}
+    if ssl:
+        ref_w = P.synth.FrameFeatureExtractor().weight
+        assert torch.equal(G.encoder.cmodel.weight.detach().cpu(), ref_w), 'the frozen extractor must not be touched by the optimizer'
 
     # ---------------- the updates themselves (summary kept under gpurun_out/ as evidence)
     import json
@@ -116,7 +131,7 @@ def test_full_iteration_vs_oracle(cfg_name, B, dev):
                           rest_q95=float(np.quantile(rs_, 0.95)), rest_max=float(rs_.max()), tensors=len(st))
     summ['losses'] = {k: float(v) for k, v in log.items()}
     summ['kernels_d_step'], summ['kernels_g_step'] = sorted(tr_d.names), sorted(tr_g.names)
-    json.dump(summ, open(os.path.join(out_dir, f'step_stats_{cfg_name}_B{B}.json'), 'w'), indent=1)
+    json.dump(summ, open(os.path.join(out_dir, f'step_stats_{cfg_name}_B{B}_T{T}.json'), 'w'), indent=1)
     for name, st, lr in (('D', st_d, cfg.lr_d), ('G', st_g, cfg.lr_g)):
         flipped = np.array([v[0] for v in st.values()])
         rest = np.array([v[1] for v in st.values()])
@@ -128,6 +143,6 @@ def test_full_iteration_vs_oracle(cfg_name, B, dev):
         assert float(np.median(rest)) <= 5e-3 and float(np.quantile(rest, 0.95)) <= 3e-2, (name, float(np.median(rest)), float(np.quantile(rest, 0.95)))
     # dead parameters are untouched on both sides
     for k, p in G.named_parameters():
-        if ost.g[k].grad is None:
+        if k in ost.g and ost.g[k].grad is None:
             assert torch.equal(p.detach().cpu(), sd_g[k]), k
     print(f'\n[{cfg_name} B={B}] kernel instances: D-step {len(tr_d.names)}, G-step {len(tr_g.names)}')
