@@ -117,7 +117,7 @@ def kernel_table(pkg, dev, B, step_ms, iters=40, manifest=None):
         e['frac'] = e['achieved'] / e['peak']
         rows.append(e)
 
-    def conv_case(label, n, bound, cin, cout, k, dil, T, reflect, pre, which, Bc, post=0, film=False, bias3=False):
+    def conv_case(label, n, bound, cin, cout, k, dil, T, reflect, pre, which, Bc, post=0, film=False, bias3=False, bits=False):
         pad = (k - 1) * dil // 2
         spec = ops.ConvSpec(cin, cout, k, 1, pad, dil, 1, reflect)
         w = torch.randn(cout, cin, k, device=dev) / (cin * k) ** 0.5
@@ -132,14 +132,15 @@ def kernel_table(pkg, dev, B, step_ms, iters=40, manifest=None):
             shapes = dict(x=(Bc, cin, T), y=(Bc, cout, T))
             if film:
                 shapes.update(gb=(Bc, 2 * cin, T), res=(Bc, cout, T))
-            words = cin + cout + ((2 * cin + cout) if film else 0)
+            words = cin + cout + ((2 * cin + cout) if film else 0) + (cout / 32.0 if bits else 0)
         elif which == 'dgrad':
             shapes = dict(dy=(Bc, cout, T), dx=(Bc, cin, T))
-            if pre:
+            if pre and not bits:
                 shapes['x_in'] = (Bc, cin, T)
             if post:
                 shapes['act'] = (Bc, cout, T)
-            words = cout + cin + (cin if pre else 0) + (cout if post else 0)
+            # bits: the LeakyReLU mask comes as 1 bit per element (tdvc_conv_dgrad_args.x_sign_bits), like the step passes it
+            words = cout + cin + ((cin / 32.0 if bits else cin) if pre else 0) + (cout if post else 0)
         else:
             shapes = dict(x=(Bc, cin, T), dy=(Bc, cout, T))
             if post:
@@ -148,14 +149,17 @@ def kernel_table(pkg, dev, B, step_ms, iters=40, manifest=None):
         bufs = Bufs(torch, dev, shapes)
         keep.append(bufs)
         calls = []
-        for s in bufs.sets:
+        nbw = (cin if which == 'dgrad' else cout)
+        bitbufs = [torch.randint(-2 ** 31, 2 ** 31 - 1, (Bc, nbw, T // 32), dtype=torch.int32, device=dev) for _ in bufs.sets] if bits else [None] * bufs.n
+        keep.append(bitbufs)
+        for s, bw in zip(bufs.sets, bitbufs):
             dyxf = (lambda s=s: ops._xf(L.XF_MASK_LRELU, aux=s['act'])) if post else (lambda s=s: ops._xf())
             if which == 'fwd':
                 xf = ops._xf(L.XF_FILM_LRELU, aux=s['gb']) if film else ops._xf(L.XF_LRELU if pre else L.XF_NONE)
-                calls.append(lambda s=s, xf=xf: ops.conv_fwd_raw(spec, s['x'], xf, post=post, res=s.get('res'), out=s['y'], bias3=k3b))
+                calls.append(lambda s=s, xf=xf, bw=bw: ops.conv_fwd_raw(spec, s['x'], xf, post=post, res=s.get('res'), out=s['y'], bias3=k3b, sign_bits=bw))
             elif which == 'dgrad':
-                calls.append(lambda s=s, f=dyxf: ops.conv_dgrad_raw(spec, s['dy'], f(), T, L.DG_MASK_LRELU if pre else L.DG_PLAIN,
-                                                                    x_in=s.get('x_in'), out=s['dx']))
+                calls.append(lambda s=s, f=dyxf, bw=bw: ops.conv_dgrad_raw(spec, s['dy'], f(), T, L.DG_MASK_LRELU if pre else L.DG_PLAIN,
+                                                                           x_in=s.get('x_in'), out=s['dx'], x_bits=bw))
             else:
                 xf = ops._xf(L.XF_LRELU if pre else L.XF_NONE)
                 calls.append(lambda s=s, xf=xf, f=dyxf: ops.conv_wgrad_raw(spec, s['x'], xf, s['dy'], f()))
@@ -204,12 +208,13 @@ def kernel_table(pkg, dev, B, step_ms, iters=40, manifest=None):
     stages = [(32, 16000), (64, 8000), (128, 4000), (256, 500)]          # (2C, T) of the four decoder stages
     for C2, T in stages:
         tag = f'136->{C2} k3 T={T} B={BL}'
-        conv_case(f'FiLM cond_var.2 input-grad {tag}', 9, 'mfma', 136, C2, 3, 1, T, False, 1, 'dgrad', BL)
+        sb = ops.SIGN_BIT_MASKS and T % 32 == 0 and T >= 512      # the step's formulation (ops.FilmCondFn)
+        conv_case(f'FiLM cond_var.2 input-grad {tag}' + (' (1-bit LeakyReLU mask)' if sb else ''), 9, 'mfma', 136, C2, 3, 1, T, False, 1, 'dgrad', BL, bits=sb)
         if ops.FUSED_COND_FWD:
             cond_fwd_case(f'FiLM conditioning fwd (cond_var.0 fused into cond_var.2) {tag}', 9, C2, T, BL)
         else:       # the step's default: two launches
-            conv_case(f'FiLM cond_var.0 excitation window 8->136 k3 T={T} B={BL} fwd (+ 3-valued embedding bias)', 9, 'hbm', 8, 136, 3, 1, T, False, 0,
-                      'fwd', BL, bias3=True)
+            conv_case(f'FiLM cond_var.0 excitation window 8->136 k3 T={T} B={BL} fwd (+ 3-valued embedding bias' + (', sign bits out)' if sb else ')'), 9, 'hbm',
+                      8, 136, 3, 1, T, False, 0, 'fwd', BL, bias3=True, bits=sb)
             conv_case(f'FiLM cond_var.2 fwd {tag} (LeakyReLU on load)', 9, 'mfma', 136, C2, 3, 1, T, False, 1, 'fwd', BL)
         conv_case(f'FiLM cond_var.2 weight-grad {tag}', 9, 'mfma', 136, C2, 3, 1, T, False, 1, 'wgrad', BL)
         cond0_bwd_case(f'FiLM cond_var.0 backward (dexc + dW window + dk3) 136ch T={T} B={BL}', 9, T, BL)

@@ -78,6 +78,10 @@ typedef struct {
   const float* add; int64_t add_bs;  /* optional running sum (MRF mean, model/generator.py:192-193) */
   float* y; int64_t y_bs;
   const float* bias3;                /* optional [B][Cout][3]: per-sample bias for t==0 / interior / t==Tout-1 */
+  uint32_t* sign_bits; int64_t sign_bits_bs; /* optional output [B][Cout][Tout/32] (batch stride in words): bit t%32 of word t/32 =
+                                        (y[b][co][t] > 0) -- a 32x smaller LeakyReLU mask source for the input-grad of the NEXT layer
+                                        (tdvc_conv_dgrad_args.x_sign_bits). Needs a stride-1 conv, Tout % 32 == 0, Tout > 80, 16-byte
+                                        aligned operands (TDVC_EUNSUPPORTED otherwise) */
 } tdvc_conv_fwd_args;
 
 typedef struct {
@@ -92,6 +96,9 @@ typedef struct {
   float* dgb; int64_t dgb_bs;        /* FiLM gradient out [B][2C][T] (TDVC_DG_FILM) */
   const float* add; int64_t add_bs; float add_scale; /* dx += add_scale*add (residual path gradient) */
   float* dx; int64_t dx_bs;
+  const uint32_t* x_sign_bits; int64_t x_sign_bits_bs; /* optional, TDVC_DG_MASK_LRELU: the sign bits of x_in as written by
+                                        tdvc_conv_fwd_args.sign_bits ([B][Cin][Tin/32]); read instead of x_in (which may then be NULL).
+                                        Same shape limits as sign_bits */
 } tdvc_conv_dgrad_args;
 
 typedef struct {

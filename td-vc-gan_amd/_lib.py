@@ -29,7 +29,7 @@ class ConvFwdArgs(C.Structure):
     _fields_ = [('x', C.c_void_p), ('x_bs', C.c_int64), ('x_xf', Xform), ('w', C.c_void_p), ('bias', C.c_void_p),
                 ('res', C.c_void_p), ('res_bs', C.c_int64), ('post_act', C.c_int32), ('post_slope', C.c_float),
                 ('out_scale', C.c_float), ('add', C.c_void_p), ('add_bs', C.c_int64), ('y', C.c_void_p),
-                ('y_bs', C.c_int64), ('bias3', C.c_void_p)]
+                ('y_bs', C.c_int64), ('bias3', C.c_void_p), ('sign_bits', C.c_void_p), ('sign_bits_bs', C.c_int64)]
 
 
 class FilmCondArgs(C.Structure):
@@ -51,7 +51,7 @@ class ConvDgradArgs(C.Structure):
                 ('epilogue', C.c_int32), ('x_in', C.c_void_p), ('x_in_bs', C.c_int64), ('slope', C.c_float),
                 ('gb', C.c_void_p), ('gb_bs', C.c_int64), ('dgb', C.c_void_p), ('dgb_bs', C.c_int64),
                 ('add', C.c_void_p), ('add_bs', C.c_int64), ('add_scale', C.c_float),
-                ('dx', C.c_void_p), ('dx_bs', C.c_int64)]
+                ('dx', C.c_void_p), ('dx_bs', C.c_int64), ('x_sign_bits', C.c_void_p), ('x_sign_bits_bs', C.c_int64)]
 
 
 class ConvWgradArgs(C.Structure):

@@ -140,6 +140,7 @@ extern "C" int tdvc_conv_fwd(const tdvc_conv_desc* d, const tdvc_conv_fwd_args* 
       q.T = d->Tin; q.Cin = d->Cin; q.Cout = d->Cout; q.Cw = cw; q.K = d->K; q.d = d->dilation; q.pad = d->pad; q.reflect = d->reflect;
       q.post = a->post_act; q.slope = slope; q.in_scale = scale; q.out_scale = a->out_scale == 0.f ? 1.f : a->out_scale;
       q.add_scale = 1.f; q.m_slope = a->post_slope;
+      q.sbits = a->sign_bits; q.sb_bs = (int)a->sign_bits_bs;
       q.vec = ((d->Tin & 3) == 0 && vec_ptr(a->x, a->x_bs) && vec_ptr(a->y, a->y_bs) && vec_ptr(a->res, a->res_bs) &&
                vec_ptr(a->add, a->add_bs) && vec_ptr(aux, aux_bs)) ? 1 : 0;
       if (!q.vec && d->Tin > 80) goto generic_fwd;
@@ -149,6 +150,7 @@ extern "C" int tdvc_conv_fwd(const tdvc_conv_desc* d, const tdvc_conv_fwd_args* 
     }
   }
 generic_fwd:
+  if (a->sign_bits) return tdvc_fail(TDVC_EUNSUPPORTED, "conv_fwd: sign_bits needs a stride-1 conv with Tout % 32 == 0, Tout > 80 and 16-byte aligned operands");
   GemmConvP p = {};
   p.x.p = a->x; p.x.bs = a->x_bs; p.x.T = d->Tin; p.x.Cg = Cin_g; p.x.xf = to_xf(a->x_xf);
   p.w = a->w; p.K = d->K; p.s = d->stride; p.pad = d->pad; p.groups = d->groups;
@@ -195,22 +197,31 @@ extern "C" int tdvc_conv_dgrad(const tdvc_conv_desc* d, const tdvc_conv_dgrad_ar
     const int epi = a->epilogue == TDVC_DG_PLAIN ? EPI_PLAIN : (a->epilogue == TDVC_DG_MASK_LRELU ? EPI_MASK : EPI_FILM);
     if (xfk >= 0 && (cw & 3) == 0 && al16(w) && ok_bs(a->dy, a->dy_bs) && ok_bs(a->dx, a->dx_bs) && ok_bs(a->add, a->add_bs) &&
         ok_bs(aux, aux_bs) && ok_bs(a->x_in, a->x_in_bs) && ok_bs(a->gb, a->gb_bs) && ok_bs(a->dgb, a->dgb_bs) &&
-        (epi == EPI_PLAIN || a->x_in) && (epi != EPI_FILM || (a->gb && a->dgb))) {
+        (epi == EPI_PLAIN || a->x_in || (epi == EPI_MASK && a->x_sign_bits)) && (epi != EPI_FILM || (a->gb && a->dgb))) {
       q.x = a->dy; q.w = w; q.y = a->dx; q.add = a->add; q.aux = aux; q.mx = a->x_in; q.gb = a->gb; q.dgb = a->dgb;
       q.x_bs = (int)a->dy_bs; q.y_bs = (int)a->dx_bs; q.add_bs = (int)a->add_bs; q.aux_bs = (int)aux_bs; q.mx_bs = (int)a->x_in_bs;
       q.gb_bs = (int)a->gb_bs; q.dgb_bs = (int)a->dgb_bs;
       q.T = d->Tin; q.Cin = d->Cout; q.Cout = d->Cin; q.Cw = cw; q.K = d->K; q.d = d->dilation;
       q.pad = (d->K - 1) * d->dilation - d->pad; q.flip = 1; q.mirror = d->reflect ? d->pad : 0;
       q.slope = slope; q.in_scale = scale; q.out_scale = 1.f; q.add_scale = a->add_scale; q.m_slope = a->slope;
+      if (epi == EPI_MASK && a->x_sign_bits) { q.mbits = a->x_sign_bits; q.mb_bs = (int)a->x_sign_bits_bs; }
       q.vec = ((d->Tin & 3) == 0 && vec_ptr(a->dy, a->dy_bs) && vec_ptr(a->dx, a->dx_bs) && vec_ptr(a->add, a->add_bs) && vec_ptr(aux, aux_bs) &&
                vec_ptr(a->x_in, a->x_in_bs) && vec_ptr(a->gb, a->gb_bs) && vec_ptr(a->dgb, a->dgb_bs)) ? 1 : 0;
       if (!q.vec && d->Tin > 80) goto generic_dgrad;
       hipError_t e = launch_conv_lean(q, d->B, xfk, epi, (hipStream_t)stream);
       if (e == hipSuccess) return TDVC_OK;
       if (e != hipErrorNotSupported) return tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));
+      if (q.mbits && a->x_in) {   // shape outside the sign-bit path: the fp32 mask source does the same job
+        q.mbits = nullptr;
+        e = launch_conv_lean(q, d->B, xfk, epi, (hipStream_t)stream);
+        if (e == hipSuccess) return TDVC_OK;
+        if (e != hipErrorNotSupported) return tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));
+      }
     }
   }
 generic_dgrad:
+  if (a->epilogue == TDVC_DG_MASK_LRELU && !a->x_in && a->x_sign_bits)
+    return tdvc_fail(TDVC_EUNSUPPORTED, "conv_dgrad: x_sign_bits without x_in needs a stride-1 conv with Tin % 32 == 0, Tin > 80 and 16-byte aligned operands");
   GemmConvP p = {};
   p.x.p = a->dy; p.x.bs = a->dy_bs; p.x.T = d->Tout; p.x.Cg = Cout_g; p.x.xf = to_xf(a->dy_xf);
   p.w = a->w; p.K = d->K; p.s = d->stride; p.groups = d->groups;

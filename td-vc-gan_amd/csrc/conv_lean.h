@@ -18,6 +18,8 @@ struct LeanP {
   int post;
   const float* cw; const float* k3; float* cv0;   // LXF_COND: cond_var.0 excitation-window weights, edge bias, cv0 output
   int cw_stride, Cv, cv0_bs, ES;
+  unsigned* sbits; const unsigned* mbits;   // sign-bit output of the forward epilogue / sign-bit mask source of EPI_MASK ([B][C][T/32] words)
+  int sb_bs, mb_bs;                    // their batch strides in words
   int swz;                             // XCD-aware block order (see conv_lean_kernel)
   int vec;                             // host-checked: T % 4 == 0, every pointer 16-byte aligned, batch strides % 4 == 0
   float slope, in_scale, out_scale, add_scale, m_slope;

@@ -52,6 +52,7 @@ __device__ __forceinline__ float lean_fetch(const LeanP& p, int b, int c, int q)
 // registers), 3 for 32 x 256, 4 for the rest -- including the 64 x 64 tile (16 accumulator registers), whose 1024-block
 // grids (D layer 5) then run as ONE round instead of 1.33 rounds of 768 slots.
 constexpr int lean_min_blocks(int m_rep, int n_rep, int wm, int xfk) {
+  if (m_rep == 1 && n_rep == 4 && wm == 1 && xfk == LXF_ACT) return 5;   // 16 x 256 tile, plain prologue: 5 resident blocks (<= 96 VGPRs) is what the HBM-bound convs run at
   return m_rep * n_rep >= 9 ? 2 : ((m_rep * n_rep >= 8 || (wm == 4 && xfk == LXF_FILM)) ? 3 : LEAN_OCC_SMALL);   // (FiLM prologue on 64 x 64: 12 spills at 4)
 }
 template <int M_REP, int N_REP, int WM, int WN, int XFK, int EPI>
@@ -452,61 +453,87 @@ __global__ __launch_bounds__(256, lean_min_blocks(M_REP, N_REP, WM, XFK)) void c
     }
     return;
   }
+  // One float4 of the output: channel co, time steps t0 .. t0+3 (all inside the tensor). Returns the stored values.
+  auto epi_store = [&](f32x4 v, const int co, const int t0, const float bias) -> f32x4 {
+    const long oi = (long)co * p.T + t0;
+    if (EPI == EPI_FWD) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] += bias;
+      if (p.bias3) {
+        const float* k3 = p.bias3 + ((long)b * p.Cout + co) * 3;
+        const float mid = k3[1];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] += mid;
+        if (t0 == 0) v[0] += k3[0] - mid;
+        if (t0 + 4 == p.T) v[3] += k3[2] - mid;
+      }
+      if (p.res) { const f32x4 r = *reinterpret_cast<const f32x4*>(p.res + (long)b * p.res_bs + oi); v += r; }
+      if (p.post == POST_LRELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], v[q] * p.m_slope);
+      } else if (p.post == POST_TANH) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = tanhf(v[q]);
+      }
+      v *= p.out_scale;
+    } else if (EPI == EPI_MASK) {
+      if (N_REP >= 2 && p.mbits) {   // sign bits instead of the fp32 mask source: one word per 32 time steps (host: T % 32 == 0)
+        const unsigned wbits = p.mbits[(long)b * p.mb_bs + (long)co * (p.T >> 5) + (t0 >> 5)] >> (t0 & 31);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = ((wbits >> q) & 1u) ? v[q] : v[q] * p.m_slope;
+      } else {
+        const f32x4 mm = *reinterpret_cast<const f32x4*>(p.mx + (long)b * p.mx_bs + oi);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = mm[q] > 0.f ? v[q] : v[q] * p.m_slope;
+      }
+    } else if (EPI == EPI_FILM) {
+      const f32x4 h = *reinterpret_cast<const f32x4*>(p.mx + (long)b * p.mx_bs + oi);
+      const float* gp = p.gb + (long)b * p.gb_bs + oi;
+      const f32x4 ga = *reinterpret_cast<const f32x4*>(gp);
+      const f32x4 be = *reinterpret_cast<const f32x4*>(gp + (long)p.Cout * p.T);
+      f32x4 dga, dbe;
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const float h2 = h[q] * (1.f + ga[q]) + be[q];
+        const float dh2 = h2 > 0.f ? v[q] : v[q] * p.m_slope;
+        dga[q] = dh2 * h[q]; dbe[q] = dh2; v[q] = dh2 * (1.f + ga[q]);
+      }
+      float* dg = p.dgb + (long)b * p.dgb_bs + oi;
+      *reinterpret_cast<f32x4*>(dg) = dga;
+      *reinterpret_cast<f32x4*>(dg + (long)p.Cout * p.T) = dbe;
+    }
+    if (p.add) { const f32x4 a4 = *reinterpret_cast<const f32x4*>(p.add + (long)b * p.add_bs + oi); v += a4 * p.add_scale; }
+    *reinterpret_cast<f32x4*>(p.y + (long)b * p.y_bs + oi) = v;
+    return v;
+  };
+  auto sign_nibble = [](const f32x4& v, const int t0) -> unsigned {   // this float4's sign bits at their place in the 32-step word
+    return ((v[0] > 0.f ? 1u : 0u) | (v[1] > 0.f ? 2u : 0u) | (v[2] > 0.f ? 4u : 0u) | (v[3] > 0.f ? 8u : 0u)) << (t0 & 31);
+  };
+
 #pragma unroll
   for (int m = 0; m < M_REP; ++m) {
     const int co = r0 + wrow0 + m * 16 + ln;
     if (co >= p.Cout) continue;
-    const long ro = (long)co * p.T;
     float bias = 0.f;
     if (EPI == EPI_FWD && p.bias) bias = p.bias[co];
+    unsigned sb_word = 0;
 #pragma unroll
     for (int n = 0; n < N_REP; ++n) {
       const int t0 = n0 + wcol0 + n * 16 + kq * 4;
       if (t0 >= p.T) continue;
-      const long oi = ro + t0;
-      f32x4 v = acc[m][n];
-      if (EPI == EPI_FWD) {
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] += bias;
-        if (p.bias3) {
-          const float* k3 = p.bias3 + ((long)b * p.Cout + co) * 3;
-          const float mid = k3[1];
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] += mid;
-          if (t0 == 0) v[0] += k3[0] - mid;
-          if (t0 + 4 == p.T) v[3] += k3[2] - mid;
+      const f32x4 v = epi_store(acc[m][n], co, t0, bias);
+      if (EPI == EPI_FWD && N_REP >= 2 && p.sbits) {
+        // sign bits of the stored values: the 4 lanes (kq = 0..3) of a channel are OR-ed with two wave shuffles, and sub-tiles
+        // (n, n+1) make one 32-bit word (the wave's first column is a multiple of 32: 16 * N_REP columns per wave, N_REP even)
+        const unsigned h = sign_nibble(v, t0);
+        sb_word = (n & 1) ? (sb_word | h) : h;
+        if (n & 1) {
+          unsigned w = sb_word;
+          w |= (unsigned)__shfl_xor((int)w, 16);
+          w |= (unsigned)__shfl_xor((int)w, 32);
+          if (kq == 0) p.sbits[(long)b * p.sb_bs + (long)co * (p.T >> 5) + (t0 >> 5)] = w;
         }
-        if (p.res) { const f32x4 r = *reinterpret_cast<const f32x4*>(p.res + (long)b * p.res_bs + oi); v += r; }
-        if (p.post == POST_LRELU) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = fmaxf(v[q], v[q] * p.m_slope);
-        } else if (p.post == POST_TANH) {
-#pragma unroll
-          for (int q = 0; q < 4; ++q) v[q] = tanhf(v[q]);
-        }
-        v *= p.out_scale;
-      } else if (EPI == EPI_MASK) {
-        const f32x4 mm = *reinterpret_cast<const f32x4*>(p.mx + (long)b * p.mx_bs + oi);
-#pragma unroll
-        for (int q = 0; q < 4; ++q) v[q] = mm[q] > 0.f ? v[q] : v[q] * p.m_slope;
-      } else if (EPI == EPI_FILM) {
-        const f32x4 h = *reinterpret_cast<const f32x4*>(p.mx + (long)b * p.mx_bs + oi);
-        const float* gp = p.gb + (long)b * p.gb_bs + oi;
-        const f32x4 ga = *reinterpret_cast<const f32x4*>(gp);
-        const f32x4 be = *reinterpret_cast<const f32x4*>(gp + (long)p.Cout * p.T);
-        f32x4 dga, dbe;
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const float h2 = h[q] * (1.f + ga[q]) + be[q];
-          const float dh2 = h2 > 0.f ? v[q] : v[q] * p.m_slope;
-          dga[q] = dh2 * h[q]; dbe[q] = dh2; v[q] = dh2 * (1.f + ga[q]);
-        }
-        float* dg = p.dgb + (long)b * p.dgb_bs + oi;
-        *reinterpret_cast<f32x4*>(dg) = dga;
-        *reinterpret_cast<f32x4*>(dg + (long)p.Cout * p.T) = dbe;
       }
-      if (p.add) { const f32x4 a4 = *reinterpret_cast<const f32x4*>(p.add + (long)b * p.add_bs + oi); v += a4 * p.add_scale; }
-      *reinterpret_cast<f32x4*>(p.y + (long)b * p.y_bs + oi) = v;
     }
   }
   PROF(6)
@@ -613,6 +640,10 @@ hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st) {
     for (const Cand& c : cands)
       if (c.cfg == g_force_tile) { MT = c.MT; NT = c.NT; cfg = c.cfg; }
     if (g_force_tile == tall.cfg) { MT = tall.MT; NT = tall.NT; cfg = tall.cfg; }
+  }
+  if (p.sbits || p.mbits) {   // sign-bit words span two 16-column sub-tiles of one wave: not on the tiles with one sub-tile per wave
+    if (!p.vec || (p.T & 31) || p.T <= 80) return hipErrorNotSupported;
+    if (cfg == 3 || cfg == tall.cfg) { MT = 16; NT = 256; cfg = 0; }
   }
   const int first = -p.pad;
   int lo = -p.pad - p.mirror;

@@ -105,7 +105,7 @@ def _check_layout(t):
 
 
 def conv_fwd_raw(spec: ConvSpec, x, x_xf, post=L.POST_NONE, res=None, add=None, out_scale=1.0, out=None, w_ptr=None, b_ptr=None,
-                 bias3=None):
+                 bias3=None, sign_bits=None):
     B, _, tin = x.shape
     d = spec.desc(B, tin)
     y = out if out is not None else torch.empty((B, spec.cout, d.Tout), dtype=torch.float32, device=x.device)
@@ -115,13 +115,14 @@ def conv_fwd_raw(spec: ConvSpec, x, x_xf, post=L.POST_NONE, res=None, add=None, 
                       res.data_ptr() if res is not None else None, _bs(res) if res is not None else 0,
                       post, SLOPE, out_scale, add.data_ptr() if add is not None else None,
                       _bs(add) if add is not None else 0, y.data_ptr(), _bs(y),
-                      bias3.data_ptr() if bias3 is not None else None)
+                      bias3.data_ptr() if bias3 is not None else None,
+                      sign_bits.data_ptr() if sign_bits is not None else None, _bs(sign_bits) if sign_bits is not None else 0)
     L.check(L.lib().tdvc_conv_fwd(C.byref(d), C.byref(a), _stream(x)))
     return y
 
 
 def conv_dgrad_raw(spec: ConvSpec, dy, dy_xf, tin, epilogue=L.DG_PLAIN, x_in=None, gb=None, dgb=None, add=None,
-                   add_scale=1.0, out=None):
+                   add_scale=1.0, out=None, x_bits=None):
     B = dy.shape[0]
     d = spec.desc(B, tin)
     dx = out if out is not None else torch.empty((B, spec.cin, tin), dtype=torch.float32, device=dy.device)
@@ -131,7 +132,8 @@ def conv_dgrad_raw(spec: ConvSpec, dy, dy_xf, tin, epilogue=L.DG_PLAIN, x_in=Non
                         gb.data_ptr() if gb is not None else None, _bs(gb) if gb is not None else 0,
                         dgb.data_ptr() if dgb is not None else None, _bs(dgb) if dgb is not None else 0,
                         add.data_ptr() if add is not None else None, _bs(add) if add is not None else 0, add_scale,
-                        dx.data_ptr(), _bs(dx))
+                        dx.data_ptr(), _bs(dx),
+                        x_bits.data_ptr() if x_bits is not None else None, _bs(x_bits) if x_bits is not None else 0)
     L.check(L.lib().tdvc_conv_dgrad(C.byref(d), C.byref(a), _stream(dy)))
     return dx
 
@@ -264,6 +266,7 @@ class FilmBlockFn(Function):
 
 
 FUSED_COND_FWD = os.environ.get('TDVC_FUSED_COND_FWD', '0') == '1'     # single-launch conditioning forward (tdvc_film_cond_fwd)
+SIGN_BIT_MASKS = os.environ.get('TDVC_SIGN_BIT_MASKS', '1') == '1'     # cond_var.2 input-grad reads 1-bit LeakyReLU masks (A/B switch)
 
 
 class FilmCondFn(Function):
@@ -277,6 +280,7 @@ class FilmCondFn(Function):
         exc, k3 = exc.contiguous(), k3.contiguous()
         B, nv, T = exc.shape
         nc = spec2.cin
+        bits = None
         if FUSED_COND_FWD:
             cv0 = torch.empty((B, nc, T), dtype=torch.float32, device=exc.device)
             gb = torch.empty((B, spec2.cout, T), dtype=torch.float32, device=exc.device)
@@ -287,9 +291,14 @@ class FilmCondFn(Function):
             # two launches: the 8-channel excitation window of cond_var.0 (HBM-bound, writes the 136-channel intermediate
             # once) and cond_var.2 on it with LeakyReLU-on-load. Measured faster than the single fused launch at every
             # decoder stage once the plain kernel runs 3 blocks per CU (tools/tile_sweep.py).
-            cv0 = conv_fwd_raw(spec_var, exc, _xf(), bias3=k3)
+            # the input-grad of cond_var.2 only needs the SIGN of cv0 (LeakyReLU mask): one bit per element, written by the
+            # launch that produces cv0, instead of re-reading the 136-channel fp32 tensor (the largest of the step)
+            if SIGN_BIT_MASKS and T % 32 == 0 and T >= 512:
+                bits = torch.empty((B, nc, T // 32), dtype=torch.int32, device=exc.device)
+            cv0 = conv_fwd_raw(spec_var, exc, _xf(), bias3=k3, sign_bits=bits)
             gb = conv_fwd_raw(spec2, cv0, _xf(L.XF_LRELU))
         ctx.sv, ctx.s2 = spec_var, spec2
+        ctx.bits = bits
         ctx.save_for_backward(exc, cv0)
         return gb
 
@@ -299,7 +308,7 @@ class FilmCondFn(Function):
         dgb = dgb.contiguous()
         B, nc, T = cv0.shape
         conv_wgrad_raw(ctx.s2, cv0, _xf(L.XF_LRELU), dgb, _xf())
-        dcv = conv_dgrad_raw(ctx.s2, dgb, _xf(), T, L.DG_MASK_LRELU, x_in=cv0)
+        dcv = conv_dgrad_raw(ctx.s2, dgb, _xf(), T, L.DG_MASK_LRELU, x_in=cv0, x_bits=ctx.bits)
         # everything that consumes d_cv0 in one pass over it: dexc, the excitation window of cond_var.0's weight-grad, dk3
         lib = L.lib()
         sv = ctx.sv.slot

@@ -185,3 +185,70 @@ def test_launch_shape_fused_conditioning(cfg, fused_fwd, dev):
     assert max(errs.values()) < TOL, (errs, sorted(tr.names))
     assert any(n.startswith('conv_lean_kernel') and n.endswith(',4,0>') for n in tr.names) == fused_fwd, sorted(tr.names)
     assert 'film_cond0_bwd_kernel' in tr.names, sorted(tr.names)
+
+
+# ------------------------------------------------------------------------------------------------ sign-bit masks
+# tdvc_conv_fwd_args.sign_bits / tdvc_conv_dgrad_args.x_sign_bits: the forward epilogue packs (y > 0) into one bit per element,
+# the LeakyReLU-mask epilogue of the next layer's input-grad reads those words instead of the fp32 tensor (FiLM conditioning:
+# cond_var.0 -> LeakyReLU -> cond_var.2). Exact by construction: the bits must equal (y > 0) and the input-grad must be
+# bit-identical to the one computed from the fp32 mask source -- on every tile that can carry the words (two or four
+# 16-column sub-tiles per wave), with a partial channel tile (40 = 2.5 x 16), a partial time tile and a 3-valued edge bias.
+SIGN_CFG = [-1, 0, 1, 2, 4, 5, 6, 3]      # 3 = one sub-tile per wave: the launcher must move to the 16 x 256 tile
+
+
+@pytest.mark.parametrize('cfg', SIGN_CFG, ids=[f'tile{c}' for c in SIGN_CFG])
+def test_sign_bit_masks(cfg, dev):
+    P = importlib.import_module('td-vc-gan_amd')
+    ops, arena, L = P.ops, P.arena, P._lib
+    torch.manual_seed(100 + cfg)
+    B, cin, cmid, cout, T = 3, 8, 40, 24, 544
+    w0 = (torch.randn(cmid, cin, 3) / (cin * 3) ** 0.5).to(dev)
+    b0 = (torch.randn(cmid) * 0.1).to(dev)
+    k3 = (torch.randn(B, cmid, 3) * 0.3).to(dev)
+    w2 = (torch.randn(cout, cmid, 3) / (cmid * 3) ** 0.5).to(dev)
+    w2t = w2.permute(1, 0, 2).contiguous()
+    s0 = ops.ConvSpec(cin, cmid, 3, 1, 1, 1, 1, False)
+    s0.slot = arena.ConvSlot(w0.data_ptr(), b0.data_ptr(), 0, 0, False, None, 0)
+    s2 = ops.ConvSpec(cmid, cout, 3, 1, 1, 1, 1, False)
+    s2.slot = arena.ConvSlot(w2.data_ptr(), 0, 0, 0, False, None, w2t.data_ptr())
+    x = torch.randn(B, cin, T, device=dev)
+    dy = torch.randn(B, cout, T, device=dev)
+    bits = torch.zeros(B, cmid, T // 32, dtype=torch.int32, device=dev)
+
+    def run():
+        y = ops.conv_fwd_raw(s0, x, ops._xf(), bias3=k3, sign_bits=bits)
+        dx_bits = ops.conv_dgrad_raw(s2, dy, ops._xf(), T, L.DG_MASK_LRELU, x_in=None, x_bits=bits)
+        dx_f32 = ops.conv_dgrad_raw(s2, dy, ops._xf(), T, L.DG_MASK_LRELU, x_in=y)
+        return y, dx_bits, dx_f32
+    if cfg >= 0:
+        (y, dx_bits, dx_f32), names = _run_forced(cfg, run)
+    else:
+        with traced() as tr:
+            y, dx_bits, dx_f32 = run()
+        names = tr.names
+    torch.cuda.synchronize()
+    want = ((y > 0).reshape(B, cmid, T // 32, 32).long() << torch.arange(32, device=dev)).sum(-1)
+    got = bits.long() & 0xFFFFFFFF
+    assert torch.equal(got, want), f'{int((got != want).sum())} sign words differ'
+    assert float((y > 0).float().mean()) > 0.2 and float((y <= 0).float().mean()) > 0.2      # the mask is not trivial
+    if cfg in (-1, 3):      # the bit launch moved to another tile than the fp32 one: another channel-chunk order, same math
+        assert float((dx_bits - dx_f32).norm() / dx_f32.norm()) < 1e-6
+    else:
+        assert torch.equal(dx_bits, dx_f32)
+    assert float(dx_bits.abs().max()) > 0
+    eff = 0 if cfg == 3 else cfg
+    if cfg >= 0:
+        assert lean_name(eff, LXF_ACT, EPI_FWD) in names and lean_name(eff, LXF_ACT, EPI_MASK) in names, sorted(names)
+
+
+def test_sign_bits_refused_outside_contract(dev):
+    """Shapes that cannot carry the words (T % 32 != 0) are refused, not silently computed without the bits."""
+    P = importlib.import_module('td-vc-gan_amd')
+    ops, arena, L = P.ops, P.arena, P._lib
+    w = torch.randn(16, 8, 3, device=dev)
+    s = ops.ConvSpec(8, 16, 3, 1, 1, 1, 1, False)
+    s.slot = arena.ConvSlot(w.data_ptr(), 0, 0, 0, False, None, 0)
+    x = torch.randn(2, 8, 500, device=dev)
+    bits = torch.zeros(2, 16, 16, dtype=torch.int32, device=dev)
+    with pytest.raises(L.TdvcError):
+        ops.conv_fwd_raw(s, x, ops._xf(), sign_bits=bits)
