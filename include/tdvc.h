@@ -215,6 +215,7 @@ int tdvc_concat_cond_bwd(const float* dc, float* demb, float* dexc, int B, int C
 int tdvc_edge_sum3(const float* d, float* out, int B, int C, int T, void* stream);
 int tdvc_axpby(const float* a, const float* b, float* y, float alpha, float beta, int64_t n, void* stream);      /* y = alpha*a + beta*b (b may be NULL) */
 int tdvc_fill(float* y, float value, int64_t n, void* stream);
+int tdvc_sum_n(const float* const* srcs, int nsrc, float* y, int64_t n, void* stream);   /* y = srcs[0] + ... + srcs[nsrc-1], 1 <= nsrc <= 16 (srcs: HOST array of device pointers, read before the call returns): the gradient of a tensor with several consumers (autograd's AccumulateGrad chain) in one pass */
 /* WaveNet gate of the SSL encoder's WN stack (model/ssl_encoder.py:8-15, fused_add_tanh_sigmoid_multiply):
  * acts[b][c][t] = tanh(xin[b][c][t] + g[b][c][t]) * sigmoid(xin[b][H+c][t] + g[b][H+c][t]); xin / g are [B][2H][T]
  * (g optional: NULL when the stack has no global conditioning, as in SSLEncoder), acts [B][H][T]; batch strides in elements.

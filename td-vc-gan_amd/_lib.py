@@ -99,6 +99,7 @@ SIGNATURES = {
     'tdvc_edge_sum3': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'tdvc_axpby': (_i, [_vp, _vp, _vp, _f, _f, _i64, _vp]),
     'tdvc_fill': (_i, [_vp, _f, _i64, _vp]),
+    'tdvc_sum_n': (_i, [_vp, C.c_int32, _vp, _i64, _vp]),
     'tdvc_gate_fwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _vp]),
     'tdvc_gate_bwd': (_i, [_vp, _i64, _vp, _i64, _vp, _i64, _vp, _i64, _i, _i, _i, _vp]),
     'tdvc_cin_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _f, _vp]),

@@ -622,6 +622,38 @@ extern "C" int tdvc_edge_sum3(const float* d, float* out, int B, int C, int T, v
   hipLaunchKernelGGL(edge_sum3_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, d, out, C, T);
   TDVC_CHECK_LAUNCH(); return TDVC_OK;
 }
+// y = sum of up to 16 tensors in one pass (reads n, writes 1): the gradient of an activation that fans out to several
+// consumers, instead of autograd's chain of n - 1 two-operand adds (each reads 2, writes 1)
+namespace { struct SumSrc { const float* p[16]; }; }
+__global__ __launch_bounds__(256) void sum_n_kernel(const SumSrc s, int nsrc, float* y, long n, int vec) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  if (vec) {
+    const long n4 = n >> 2;
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n4; i += (long)gridDim.x * 256) {
+      f4 a = reinterpret_cast<const f4*>(s.p[0])[i];
+      for (int k = 1; k < nsrc; ++k) a += reinterpret_cast<const f4*>(s.p[k])[i];
+      reinterpret_cast<f4*>(y)[i] = a;
+    }
+  } else {
+    for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) {
+      float a = s.p[0][i];
+      for (int k = 1; k < nsrc; ++k) a += s.p[k][i];
+      y[i] = a;
+    }
+  }
+}
+extern "C" int tdvc_sum_n(const float* const* srcs, int nsrc, float* y, int64_t n, void* stream) {
+  if (!srcs || !y || nsrc < 1 || nsrc > 16) return tdvc_fail(TDVC_EINVAL, "sum_n: 1..16 sources");
+  if (n <= 0) return TDVC_OK;
+  SumSrc s;
+  bool vec = (n & 3) == 0 && (((uintptr_t)y) & 15) == 0;
+  for (int k = 0; k < 16; ++k) {
+    s.p[k] = k < nsrc ? srcs[k] : nullptr;
+    if (k < nsrc && (!srcs[k] || (((uintptr_t)srcs[k]) & 15))) { if (!srcs[k]) return tdvc_fail(TDVC_EINVAL, "sum_n: null source"); vec = false; }
+  }
+  hipLaunchKernelGGL(sum_n_kernel, dim3(tdvc_grid(vec ? n / 4 : n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, s, nsrc, y, (long)n, vec ? 1 : 0);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
 extern "C" int tdvc_axpby(const float* a, const float* b, float* y, float alpha, float beta, int64_t n, void* stream) {
   if (n <= 0) return TDVC_OK;
   hipLaunchKernelGGL(axpby_kernel, dim3(tdvc_grid(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, a, b, y, alpha, beta, (long)n);

@@ -214,11 +214,21 @@ class MRFBlock(nn.Module):
 
     def forward(self, x, c=None):
         acc, s = None, 1.0 / len(self.blocks)
-        for branch in self.blocks:
-            xs = x
+        # x feeds every branch, the conditioning every block: their gradients come back summed in one pass each (ops.fanout)
+        nblk = sum(len(br) for br in self.blocks)
+        xin = ops.fanout(x, len(self.blocks))
+        cs = [c] * nblk
+        if isinstance(c, tuple):
+            cs = list(zip(ops.fanout(c[0], nblk), ops.fanout(c[1], nblk)))
+        elif c is not None:
+            cs = list(ops.fanout(c, nblk))
+        i = 0
+        for bi, branch in enumerate(self.blocks):
+            xs = xin[bi]
             for j, blk in enumerate(branch):
                 last = j == len(branch) - 1
-                xs = blk(xs, c, acc if last else None, s if last else 1.0)
+                xs = blk(xs, cs[i], acc if last else None, s if last else 1.0)
+                i += 1
             acc = xs
         return acc
 
@@ -316,6 +326,8 @@ class Decoder(nn.Module):
         pyr = self.get_scaled_conditioning(c_var.contiguous().float())
         if self.split_cond:   # the speaker embedding [B,128] itself: its conv over a length-3 constant signal is tdvc_film_k3
             emb3 = c.contiguous().float()
+            n_mrf = sum(isinstance(m_, MRFBlock) for m_ in self.decoder)
+            emb3s = list(ops.fanout(emb3, n_mrf))      # one alias per decoder stage
         subs = []
         scale = 0
         final_conv = len(self.decoder) - 2
@@ -325,7 +337,7 @@ class Decoder(nn.Module):
                 if head is not None:
                     subs.append(head[1](x, pre=PRE_LRELU, post=L.POST_TANH))
                 exc = pyr[len(pyr) - 1 - scale]
-                cond = (emb3, exc) if self.split_cond else ops.ConcatCondFn.apply(c, exc)
+                cond = (emb3s[scale], exc) if self.split_cond else ops.ConcatCondFn.apply(c, exc)
                 scale += 1
             if isinstance(mod, MRFBlock):
                 x = mod(x, cond)

@@ -374,6 +374,40 @@ def film_block(x, gb, acc, conv_spec, pos_spec, scale):
 
 
 # ------------------------------------------------------------------------------- small ops
+class FanOutFn(Function):
+    """n aliases of x for n consumers; the backward sums the n incoming gradients in ONE pass (tdvc_sum_n: reads n, writes 1)
+    instead of autograd's chain of n - 1 two-operand adds. Same arithmetic as the reference's implicit gradient
+    accumulation up to the order of the fp32 additions (left to right here, as autograd's chain)."""
+
+    @staticmethod
+    def forward(ctx, x, n):
+        ctx.n = n
+        return tuple(x.view_as(x) for _ in range(n))
+
+    @staticmethod
+    def backward(ctx, *grads):
+        gs = [g.contiguous() for g in grads if g is not None]
+        if not gs:
+            return None, None
+        if len(gs) == 1:
+            return gs[0], None
+        out = torch.empty_like(gs[0])
+        done = None
+        for i in range(0, len(gs), 15):      # 16 sources per launch: the running sum + 15 new ones
+            part = ([done] if done is not None else []) + gs[i:i + 15]
+            ptrs = (C.c_void_p * len(part))(*[t.data_ptr() for t in part])
+            L.check(L.lib().tdvc_sum_n(ptrs, len(part), out.data_ptr(), out.numel(), _stream(out)))
+            done = out
+        return out, None
+
+
+def fanout(x, n):
+    """x for n consumers (see FanOutFn); plain aliases when no gradient flows."""
+    if n <= 1 or not (torch.is_grad_enabled() and x.requires_grad):
+        return (x,) * n
+    return FanOutFn.apply(x, n)
+
+
 class L2NormFn(Function):
     @staticmethod
     def forward(ctx, x):

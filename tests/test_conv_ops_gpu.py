@@ -266,3 +266,20 @@ def film_cond_errors(cfg, dev):
     errs = dict(gb=rel_l2(gb, gbr), dexc=rel_l2(excd.grad, excr.grad), demb=rel_l2(embd.grad, embr.grad),
                 dw0=rel_l2(dw0, w0r.grad), db0=rel_l2(db0, b0r.grad), dw2=rel_l2(dw2, w2r.grad), db2=rel_l2(db2, b2r.grad))
     return errs
+
+
+def test_fanout_sum(dev):
+    """ops.fanout: n aliases forward, ONE n-ary sum backward (tdvc_sum_n), incl. the > 16-source chaining and a consumer that
+    sends no gradient."""
+    ops, L, _ = _mods()
+    for n, shape in ((3, (2, 16, 520)), (9, (3, 8, 333)), (36, (4, 128))):
+        x = torch.randn(*shape, device=dev, requires_grad=True)
+        ws = [torch.randn(*shape, device=dev) for _ in range(n)]
+        outs = ops.fanout(x, n)
+        assert all(o.data_ptr() == x.data_ptr() for o in outs)
+        sum((o * w).sum() for o, w in list(zip(outs, ws))[1:]).backward()      # consumer 0 unused: its gradient is None
+        ref = torch.stack([w.double() for w in ws[1:]]).sum(0)
+        assert rel_l2(x.grad, ref) < 1e-6
+    with torch.no_grad():
+        y = torch.randn(2, 3, device=dev)
+        assert all(o is y for o in ops.fanout(y, 4))
