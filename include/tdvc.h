@@ -236,6 +236,13 @@ int tdvc_mse_const_fwd(const float* x, int64_t n, float target, float weight, fl
 int tdvc_mse_const_bwd(const float* x, int64_t n, float target, float weight, const float* upstream, float* dx, void* stream);
 int tdvc_l1_fwd(const float* a, const float* b, int64_t n, float weight, float* loss_out, void* stream);          /* F.l1_loss, util/losses.py:63 */
 int tdvc_l1_bwd(const float* a, const float* b, int64_t n, float weight, const float* upstream, float* da, int accumulate, void* stream);
+/* All L1 terms of one loss in one launch (multiscale_feat_loss, util/losses.py:55-68: a term per discriminator feature map).
+ * pairs: HOST array read before the call returns. fwd: loss_out += sum_i weight_i / n_i * sum|a_i - b_i|;
+ * bwd: da_i = sign(a_i - b_i) * weight_i / n_i * upstream[0]; an entry with b == NULL zero-fills da (samples of a batched map
+ * the loss does not read) and is ignored by fwd. */
+typedef struct { const float* a; const float* b; float* da; int64_t n; float weight; } tdvc_l1_pair;
+int tdvc_l1_multi_fwd(const tdvc_l1_pair* pairs, int npairs, float* loss_out, void* stream);
+int tdvc_l1_multi_bwd(const tdvc_l1_pair* pairs, int npairs, const float* upstream, void* stream);
 
 /* log-mel L1 (util/losses.py:28-53 + torchaudio MelSpectrogram semantics). The two GEMMs run on
  * tdvc_conv_*: STFT = Conv1d(1 -> 2F, K=n_fft, stride=hop) with the windowed DFT basis as weight over the

@@ -54,6 +54,10 @@ class ConvDgradArgs(C.Structure):
                 ('dx', C.c_void_p), ('dx_bs', C.c_int64), ('x_sign_bits', C.c_void_p), ('x_sign_bits_bs', C.c_int64)]
 
 
+class L1Pair(C.Structure):
+    _fields_ = [('a', C.c_void_p), ('b', C.c_void_p), ('da', C.c_void_p), ('n', C.c_int64), ('weight', C.c_float)]
+
+
 class ConvWgradArgs(C.Structure):
     _fields_ = [('x', C.c_void_p), ('x_bs', C.c_int64), ('x_xf', Xform), ('dy', C.c_void_p), ('dy_bs', C.c_int64),
                 ('dy_xf', Xform), ('dw', C.c_void_p), ('dbias', C.c_void_p), ('workspace', C.c_void_p),
@@ -108,6 +112,8 @@ SIGNATURES = {
     'tdvc_mse_const_bwd': (_i, [_vp, _i64, _f, _f, _vp, _vp, _vp]),
     'tdvc_l1_fwd': (_i, [_vp, _vp, _i64, _f, _vp, _vp]),
     'tdvc_l1_bwd': (_i, [_vp, _vp, _i64, _f, _vp, _vp, _i, _vp]),
+    'tdvc_l1_multi_fwd': (_i, [_vp, _i, _vp, _vp]),
+    'tdvc_l1_multi_bwd': (_i, [_vp, _i, _vp, _vp]),
     'tdvc_reflect_pad_fwd': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'tdvc_reflect_pad_bwd': (_i, [_vp, _vp, _i, _i, _i, _vp]),
     'tdvc_power_fwd': (_i, [_vp, _vp, _i, _i, _i, _vp]),

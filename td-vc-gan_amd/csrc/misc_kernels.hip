@@ -342,6 +342,69 @@ __global__ __launch_bounds__(256) void l1_bwd_kernel(const float* a, const float
   }
 }
 
+// Multi-tensor L1 (feature matching, util/losses.py:55-68: one term per discriminator feature map): all pairs of a loss in one
+// launch. A block owns one L1M_CHUNK-element chunk of one pair (found by a scan of the chunk prefix table, <= 64 entries).
+constexpr int L1M_MAX = 64;
+constexpr long L1M_CHUNK = 16384;
+struct L1Batch { const float* a[L1M_MAX]; const float* b[L1M_MAX]; float* da[L1M_MAX]; long n[L1M_MAX]; float w[L1M_MAX]; int first[L1M_MAX + 1]; int np; };
+__device__ __forceinline__ int l1m_find(const L1Batch& q, int chunk) {
+  int d = 0;
+  while (d + 1 < q.np && chunk >= q.first[d + 1]) ++d;
+  return d;
+}
+__global__ __launch_bounds__(256) void l1_multi_fwd_kernel(const L1Batch q, float* out) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  __shared__ float sh[4];
+  const int d = l1m_find(q, blockIdx.x);
+  const long o = (long)(blockIdx.x - q.first[d]) * L1M_CHUNK;
+  const long len = min(L1M_CHUNK, q.n[d] - o);
+  const float* a = q.a[d] + o; const float* b = q.b[d] + o;
+  float s = 0.f;
+  if (((((uintptr_t)a) | ((uintptr_t)b)) & 15) == 0) {
+    const long n4 = len >> 2;
+    for (long i = threadIdx.x; i < n4; i += 256) {
+      const f4 x = reinterpret_cast<const f4*>(a)[i], y = reinterpret_cast<const f4*>(b)[i];
+      s += (fabsf(x[0] - y[0]) + fabsf(x[1] - y[1])) + (fabsf(x[2] - y[2]) + fabsf(x[3] - y[3]));
+    }
+    for (long i = (n4 << 2) + threadIdx.x; i < len; i += 256) s += fabsf(a[i] - b[i]);
+  } else {
+    for (long i = threadIdx.x; i < len; i += 256) s += fabsf(a[i] - b[i]);
+  }
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) atomicAdd(out, s * q.w[d]);
+}
+// da = sign(a - b) * w * upstream for a pair; b == nullptr: da = 0 (the samples of a batched map that the loss does not read)
+__global__ __launch_bounds__(256) void l1_multi_bwd_kernel(const L1Batch q, const float* up) {
+  typedef float f4 __attribute__((ext_vector_type(4)));
+  const int d = l1m_find(q, blockIdx.x);
+  const long o = (long)(blockIdx.x - q.first[d]) * L1M_CHUNK;
+  const long len = min(L1M_CHUNK, q.n[d] - o);
+  float* da = q.da[d] + o;
+  if (!q.b[d]) {
+    if ((((uintptr_t)da) & 15) == 0) {
+      const long n4 = len >> 2;
+      for (long i = threadIdx.x; i < n4; i += 256) reinterpret_cast<f4*>(da)[i] = (f4){0.f, 0.f, 0.f, 0.f};
+      for (long i = (n4 << 2) + threadIdx.x; i < len; i += 256) da[i] = 0.f;
+    } else {
+      for (long i = threadIdx.x; i < len; i += 256) da[i] = 0.f;
+    }
+    return;
+  }
+  const float* a = q.a[d] + o; const float* b = q.b[d] + o;
+  const float u = (up ? up[0] : 1.f) * q.w[d];
+  auto g1 = [u](float x, float y) { const float df = x - y; return df > 0.f ? u : (df < 0.f ? -u : 0.f); };
+  if (((((uintptr_t)a) | ((uintptr_t)b) | ((uintptr_t)da)) & 15) == 0) {
+    const long n4 = len >> 2;
+    for (long i = threadIdx.x; i < n4; i += 256) {
+      const f4 x = reinterpret_cast<const f4*>(a)[i], y = reinterpret_cast<const f4*>(b)[i];
+      reinterpret_cast<f4*>(da)[i] = (f4){g1(x[0], y[0]), g1(x[1], y[1]), g1(x[2], y[2]), g1(x[3], y[3])};
+    }
+    for (long i = (n4 << 2) + threadIdx.x; i < len; i += 256) da[i] = g1(a[i], b[i]);
+  } else {
+    for (long i = threadIdx.x; i < len; i += 256) da[i] = g1(a[i], b[i]);
+  }
+}
+
 // ---- log-mel helpers (the two GEMMs run on the conv kernels: STFT = strided conv with the
 // windowed DFT basis as weight, mel projection = 1x1 conv with the filterbank as weight)
 __global__ __launch_bounds__(256) void reflect_pad_kernel(const float* x, float* y, int T, int pad) {
@@ -708,6 +771,41 @@ extern "C" int tdvc_l1_fwd(const float* a, const float* b, int64_t n, float weig
 extern "C" int tdvc_l1_bwd(const float* a, const float* b, int64_t n, float weight, const float* upstream, float* da, int accumulate, void* stream) {
   hipLaunchKernelGGL(l1_bwd_kernel, dim3(tdvc_grid(n, 256, 2048)), dim3(256), 0, (hipStream_t)stream, a, b, (long)n, weight / (float)n, upstream, da, accumulate);
   TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+
+// pairs: HOST array, consumed before the call returns. fwd: loss_out += sum_i weight_i / n_i * sum|a_i - b_i| (b_i != NULL);
+// bwd: da_i = sign(a_i - b_i) * weight_i / n_i * upstream, or da_i = 0 where b_i == NULL.
+static int l1_multi(const tdvc_l1_pair* pairs, int npairs, bool bwd, float* loss_out, const float* upstream, hipStream_t st) {
+  if (!pairs || npairs < 0) return tdvc_fail(TDVC_EINVAL, "l1_multi: bad argument");
+  for (int p0 = 0; p0 < npairs; p0 += L1M_MAX) {
+    L1Batch q = {};
+    int chunks = 0;
+    for (int i = p0; i < npairs && q.np < L1M_MAX; ++i) {
+      const tdvc_l1_pair& e = pairs[i];
+      if (e.n <= 0) continue;
+      if (bwd ? !e.da || (e.b && !e.a) : (!e.a || !e.b)) {
+        if (!bwd && !e.b) continue;                  // a zero-fill entry has nothing to add to the loss
+        return tdvc_fail(TDVC_EINVAL, "l1_multi: null pointer");
+      }
+      q.a[q.np] = e.a; q.b[q.np] = e.b; q.da[q.np] = e.da; q.n[q.np] = e.n; q.w[q.np] = e.weight / (float)e.n;
+      q.first[q.np] = chunks;
+      chunks += (int)((e.n + L1M_CHUNK - 1) / L1M_CHUNK);
+      ++q.np;
+    }
+    q.first[q.np] = chunks;
+    if (!chunks) continue;
+    if (bwd) hipLaunchKernelGGL(l1_multi_bwd_kernel, dim3(chunks), dim3(256), 0, st, q, upstream);
+    else hipLaunchKernelGGL(l1_multi_fwd_kernel, dim3(chunks), dim3(256), 0, st, q, loss_out);
+    TDVC_CHECK_LAUNCH();
+  }
+  return TDVC_OK;
+}
+extern "C" int tdvc_l1_multi_fwd(const tdvc_l1_pair* pairs, int npairs, float* loss_out, void* stream) {
+  if (!loss_out) return tdvc_fail(TDVC_EINVAL, "l1_multi_fwd: null output");
+  return l1_multi(pairs, npairs, false, loss_out, nullptr, (hipStream_t)stream);
+}
+extern "C" int tdvc_l1_multi_bwd(const tdvc_l1_pair* pairs, int npairs, const float* upstream, void* stream) {
+  return l1_multi(pairs, npairs, true, nullptr, upstream, (hipStream_t)stream);
 }
 
 extern "C" int tdvc_reflect_pad_fwd(const float* x, float* y, int B, int T, int pad, void* stream) {

@@ -200,13 +200,14 @@ class L1ViewsFn(Function):
     def forward(ctx, spec, n_a, *ts):
         a, b = ts[:n_a], ts[n_a:]
         out = _ScalarOut.new(a[0])
-        lib = L.lib()
-        for ai, off, n, bi, roff in spec:
+        pairs = (L.L1Pair * len(spec))()
+        for k, (ai, off, n, bi, roff) in enumerate(spec):
             x, y = a[ai], b[bi]
             if x.shape[1:] != y.shape[1:]:
                 raise RuntimeError(f'l1 pair shape mismatch {tuple(x.shape[1:])} vs {tuple(y.shape[1:])}')
             per = x[0].numel()
-            L.check(lib.tdvc_l1_fwd(x.data_ptr() + 4 * off * per, y.data_ptr() + 4 * roff * per, n * per, 1.0, out.data_ptr(), _stream(x)))
+            pairs[k] = L.L1Pair(x.data_ptr() + 4 * off * per, y.data_ptr() + 4 * roff * per, None, n * per, 1.0)
+        L.check(L.lib().tdvc_l1_multi_fwd(pairs, len(spec), out.data_ptr(), _stream(a[0])))     # every term in one launch
         ctx.spec, ctx.n_a = spec, n_a
         ctx.save_for_backward(*ts)
         return out
@@ -215,17 +216,22 @@ class L1ViewsFn(Function):
     def backward(ctx, g):
         g = g.contiguous()
         a, b = ctx.saved_tensors[:ctx.n_a], ctx.saved_tensors[ctx.n_a:]
-        lib = L.lib()
-        grads = []
+        grads, ents = [], []
         for ai, x in enumerate(a):
-            mine = [e for e in ctx.spec if e[0] == ai]
+            mine = sorted((off, n, bi, roff) for i_, off, n, bi, roff in ctx.spec if i_ == ai)
             dx = torch.empty_like(x)
-            _fill_gaps(dx, [(off, n) for _, off, n, _, _ in mine], lib)
             per = x[0].numel()
-            for _, off, n, bi, roff in mine:
-                L.check(lib.tdvc_l1_bwd(x.data_ptr() + 4 * off * per, b[bi].data_ptr() + 4 * roff * per, n * per, 1.0, g.data_ptr(),
-                                        dx.data_ptr() + 4 * off * per, 0, _stream(x)))
+            pos = 0
+            for off, n, bi, roff in mine:      # the term's gradient on its samples, zeros on the samples no term reads
+                if off > pos:
+                    ents.append(L.L1Pair(None, None, dx.data_ptr() + 4 * pos * per, (off - pos) * per, 0.0))
+                ents.append(L.L1Pair(x.data_ptr() + 4 * off * per, b[bi].data_ptr() + 4 * roff * per, dx.data_ptr() + 4 * off * per, n * per, 1.0))
+                pos = max(pos, off + n)
+            if pos < x.shape[0]:
+                ents.append(L.L1Pair(None, None, dx.data_ptr() + 4 * pos * per, (x.shape[0] - pos) * per, 0.0))
             grads.append(dx)
+        pairs = (L.L1Pair * len(ents))(*ents)
+        L.check(L.lib().tdvc_l1_multi_bwd(pairs, len(ents), g.data_ptr(), _stream(g)))             # all maps in one launch
         return (None, None, *grads, *([None] * len(b)))
 
 

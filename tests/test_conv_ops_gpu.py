@@ -283,3 +283,35 @@ def test_fanout_sum(dev):
     with torch.no_grad():
         y = torch.randn(2, 3, device=dev)
         assert all(o is y for o in ops.fanout(y, 4))
+
+
+def test_l1_multi(dev):
+    """tdvc_l1_multi_fwd / _bwd (all feature-matching terms in one launch) against torch: ragged sizes incl. an unaligned
+    pair, a pair longer than one chunk, zero-fill entries, more pairs than one launch holds."""
+    import ctypes as C
+    _, L, _ = _mods()
+    lib = L.lib()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    rs = torch.Generator().manual_seed(5)
+    sizes = [40000, 7, 16384, 16385, 1023] + [300 + 3 * i for i in range(70)]
+    big = torch.randn(sum(sizes) + 8, generator=rs).to(dev)
+    a, b, off = [], [], 1                                  # offset 1 float: the first pairs are NOT 16-byte aligned
+    for n in sizes:
+        a.append(big[off:off + n]); off += n
+    b = [torch.randn(n, generator=rs).to(dev) for n in sizes]
+    da = [torch.full((n,), 7.0, device=dev) for n in sizes]
+    zero = torch.full((5000,), 3.0, device=dev)
+    w = [0.5 + 0.01 * i for i in range(len(sizes))]
+    ents = [L.L1Pair(x.data_ptr(), y.data_ptr(), d.data_ptr(), x.numel(), wi) for x, y, d, wi in zip(a, b, da, w)]
+    ents.insert(3, L.L1Pair(None, None, zero.data_ptr(), zero.numel(), 0.0))
+    pairs = (L.L1Pair * len(ents))(*ents)
+    out = torch.zeros(1, device=dev)
+    up = torch.tensor([1.7], device=dev)
+    L.check(lib.tdvc_l1_multi_fwd(pairs, len(ents), out.data_ptr(), st))
+    L.check(lib.tdvc_l1_multi_bwd(pairs, len(ents), up.data_ptr(), st))
+    torch.cuda.synchronize()
+    ref = sum(wi * (x.double() - y.double()).abs().mean() for x, y, wi in zip(a, b, w))
+    assert abs(float(out) - float(ref)) < 1e-5 * float(ref)
+    for x, y, d, wi in zip(a, b, da, w):
+        assert torch.allclose(d, torch.sign(x - y) * (wi * 1.7 / x.numel()), rtol=1e-6, atol=0)
+    assert float(zero.abs().max()) == 0.0
