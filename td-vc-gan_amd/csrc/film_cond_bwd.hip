@@ -39,6 +39,7 @@ constexpr int CB_NV = 18;              // float4 columns staged: aligned window 
 constexpr int CB_S = 76;               // LDS row stride of the tiles: 12 (mod 64) -> the 16 rows x 4 columns of a (b) fragment read hit 64 distinct
                                        // banks (16 distinct multiples of 4, + kq), rows are 16-byte aligned
 constexpr int CB_G = 36;               // (a): lane group kq reduces channels kq*36 + cs; 36 * 76 = 48 (mod 64) -> the 4 groups' 16-column reads are disjoint
+                                       // (alternative 74 / 40 rows apart -- conflict-free under a 32-bank half-wave model -- measured 4 % slower on the same box)
 constexpr int CB_WS = 26;              // staged weight row: 24 taps + 2 zeros
 constexpr int CB_CT = 9;               // channel tiles of 16: nc <= 144
 constexpr int CB_ROWS = CB_CT * 16;
@@ -75,7 +76,7 @@ __global__ __launch_bounds__(256, 2) void film_cond0_bwd_kernel(const Cond0BwdP 
   const int r1 = 16 + ln;
   const int e1 = (r1 / 3) * CB_S + (r1 % 3) - 1 + 4;
   // (a) B-operand column: ce = ln (< 8), else the zero pad column
-  const int wcol = ln < 8 ? ln * 3 : 24;
+  const int wcol = ln < 8 ? ln * 3 : 24;   // (lanes ln >= 8 re-reading lane ln - 8's address instead of the zero column: no gain, 2 % slower on the same box)
 
   f32x4 acc2[2][CB_CT];
 #pragma unroll
