@@ -163,16 +163,17 @@ constexpr int WT_NTC = 64;
 constexpr int WT_AS = 66;      // 2 (mod 32)
 constexpr int WT_XS = 130;     // 2 (mod 32), >= 64 + 50 + alignment slack
 
-// SCAL = false: aligned float4 prefetch (long sequences; the chunks at the sequence ends fall back to element-wise
-// staging); SCAL = true: scalar prefetch with padding logic for every chunk (short / unaligned sequences, masked dy).
-template <int M_REP, int C_REP, int J, int D, bool SCAL>
+// SCAL = 0: aligned float4 prefetch (long sequences; the chunks at the sequence ends fall back to element-wise
+// staging); SCAL = 1: scalar prefetch with padding logic for every chunk (short / unaligned sequences, masked dy);
+// SCAL: 0 = aligned float4 staging, 1 = scalar staging with padding logic, 2 = contiguous-tile staging of short unaligned rows
+template <int M_REP, int C_REP, int J, int D, int SCAL>
 __global__ __launch_bounds__(256, 2) void conv_wgrad_tile_kernel(const WgLeanP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int MT = 32 * M_REP, CT = 32 * C_REP;
   constexpr int AV = (MT * (WT_NTC / 4) + 255) / 256;       // float4 per thread: dy rows
   constexpr int XVN = (CT * 32 + 255) / 256;                // float4 per thread: x rows (span <= 128)
-  constexpr int AS_N = SCAL ? (MT * WT_NTC + 255) / 256 : 1;   // scalars per thread (unaligned / edge chunks)
-  constexpr int XS_N = SCAL ? (CT * 128 + 255) / 256 : 1;
+  constexpr int AS_N = SCAL == 1 ? (MT * WT_NTC + 255) / 256 : 1;   // scalars per thread (unaligned / edge chunks)
+  constexpr int XS_N = SCAL == 1 ? (CT * 128 + 255) / 256 : 1;
   constexpr int AVV = SCAL ? 1 : AV, XVV = SCAL ? 1 : XVN;
   float* as = smem;                     // [MT][WT_AS]
   float* xs = smem + MT * WT_AS;        // [CT][WT_XS]
@@ -203,21 +204,82 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile_kernel(const WgLeanP p
   // mode per chunk: 2 = aligned float4 prefetch, 1 = scalar prefetch with padding logic, 0 = element-wise fallback
   const bool vec_kinds = akind <= XF_LRELU && xkind <= XF_LRELU;
   const bool sc_kinds = (akind <= XF_LRELU || akind == XF_MASK_LRELU) && xkind <= XF_LRELU && p.span <= 128;
+  constexpr bool contig = SCAL == 2;         // mode 3 below (host-checked contract)
   auto chunk_mode = [&](int q) {
     const int tile = q % p.ntiles, nc0 = tile * WT_NTC;
     if (!SCAL) return (p.vec && vec_kinds && nc0 + WT_NTC <= p.N && nc0 + p.lo >= 0 && nc0 + p.lo + p.span <= p.x.T) ? 2 : 0;
+    if (contig) return 3;
     return sc_kinds ? 1 : 0;
   };
   RegTile<AVV> ar; RegTile<XVV> xr;
   RegS<AS_N> as_r, as_a; RegS<XS_N> xs_r;
+  // Mode 3 (SCAL == 2): one whole short sequence per chunk (N = T <= 64, e.g. D layer 5: T = 63) whose rows are not 16-byte
+  // aligned. The MT (CT) rows of a tile are still ONE contiguous, 16-byte aligned run of MT*N (CT*T) floats, so they are
+  // fetched as float4 of that run (4 / 2 loads per thread instead of 16 / 9 scalar ones with per-element index arithmetic)
+  // and scattered to their (row, column) in LDS at the commit. Columns >= N of the dy tile and the halo of the x tile are
+  // zeroed once per block and never written again.
+  constexpr int AF4 = SCAL == 2 ? (MT * WT_NTC / 4 + 255) / 256 : 1, XF4 = SCAL == 2 ? (CT * WT_NTC / 4 + 255) / 256 : 1;
+  RegTile<AF4> ca, cm; RegTile<XF4> cx;
+  const int n4a = (MT * p.N) >> 2, n4x = (CT * p.x.T) >> 2;
+  auto issue_c = [&](int q) {
+    const float* abase = p.a.p + (long)q * p.a.bs + (long)r0 * p.N;
+    const float* xbase = p.x.p + (long)q * p.x.bs + (long)c0 * p.x.T;
+    const srd_t ars = make_srd(abase, n4a * 16), xrs = make_srd(xbase, n4x * 16);
+#pragma unroll
+    for (int i = 0; i < AF4; ++i) ca.v[i] = buf_load4(ars, (tid + 256 * i) * 16);
+    if (akind == XF_MASK_LRELU) {
+      const srd_t mrs = make_srd(p.a.xf.aux + (long)q * p.a.xf.aux_bs + (long)r0 * p.N, n4a * 16);
+#pragma unroll
+      for (int i = 0; i < AF4; ++i) cm.v[i] = buf_load4(mrs, (tid + 256 * i) * 16);
+    }
+#pragma unroll
+    for (int i = 0; i < XF4; ++i) cx.v[i] = buf_load4(xrs, (tid + 256 * i) * 16);
+  };
+  auto commit_c = [&]() {
+    const float invn = 1.0f / (float)p.N, invt = 1.0f / (float)p.x.T;
+    const float asl = p.a.xf.slope, asc = p.a.xf.scale, xsl = p.x.xf.slope, xsc = p.x.xf.scale;
+#pragma unroll
+    for (int i = 0; i < AF4; ++i) {
+      const int f = tid + 256 * i;
+      if (f < n4a) {
+        int row = (int)(((float)(4 * f) + 0.5f) * invn), col = 4 * f - row * p.N;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float v = ca.v[i][k];
+          if (akind == XF_LRELU) v = fmaxf(v, v * asl);
+          else if (akind == XF_MASK_LRELU) v = cm.v[i][k] > 0.f ? v : v * asl;
+          as[row * WT_AS + col] = v * asc;
+          if (++col == p.N) { col = 0; ++row; }
+        }
+      }
+    }
+#pragma unroll
+    for (int i = 0; i < XF4; ++i) {
+      const int f = tid + 256 * i;
+      if (f < n4x) {
+        int row = (int)(((float)(4 * f) + 0.5f) * invt), col = 4 * f - row * p.x.T;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          float v = cx.v[i][k];
+          if (xkind == XF_LRELU) v = fmaxf(v, v * xsl);
+          xs[row * WT_XS + col - p.lo] = v * xsc;
+          if (++col == p.x.T) { col = 0; ++row; }
+        }
+      }
+    }
+  };
+  if (contig) {
+    for (int i = tid; i < MT * WT_AS + CT * WT_XS; i += 256) smem[i] = 0.f;
+  }
   auto issue = [&](int q, int mode) {
+    if (mode == 3) { issue_c(q); return; }
     const int b = q / p.ntiles, nc0 = (q % p.ntiles) * WT_NTC;
     const float* abase = p.a.p + (long)b * p.a.bs + (long)r0 * p.a.T;
     const float* xbase = p.x.p + (long)b * p.x.bs + (long)c0 * p.x.T;
     if (!SCAL) {
       tile_issue<AVV>(ar, abase + nc0, p.a.T, avalid, MT, WT_NTC, WT_NTC, 0, tid);
       tile_issue<XVV>(xr, xbase + nc0 + p.lo, p.x.T, xvalid, CT, p.span, p.span, 0, tid);
-    } else {
+    } else if (SCAL == 1) {
       tile_issue_s<AS_N>(as_r, abase, p.N, avalid, MT, WT_NTC, nc0, 0, tid);
       if (akind == XF_MASK_LRELU)
         tile_issue_s<AS_N>(as_a, p.a.xf.aux + (long)b * p.a.xf.aux_bs + (long)r0 * p.a.T, p.N, avalid, MT, WT_NTC, nc0, 0, tid);
@@ -233,7 +295,9 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile_kernel(const WgLeanP p
     if (!SCAL && mode == 2) {
       tile_commit<AVV>(ar, nullptr, nullptr, p.a.xf, as, WT_AS, avalid, MT, WT_NTC, 0, tid);
       tile_commit<XVV>(xr, nullptr, nullptr, p.x.xf, xs, WT_XS, xvalid, CT, p.span, 0, tid);
-    } else if (SCAL && mode == 1) {
+    } else if (SCAL == 2 && mode == 3) {
+      commit_c();
+    } else if (SCAL == 1 && mode == 1) {
       tile_commit_s<AS_N>(as_r, &as_a, p.a.xf, as, WT_AS, MT, WT_NTC, tid);
       tile_commit_s<XS_N>(xs_r, nullptr, p.x.xf, xs, WT_XS, CT, p.span, tid);
     } else {
@@ -319,14 +383,15 @@ __global__ __launch_bounds__(256, 2) void conv_wgrad_tile_kernel(const WgLeanP p
   }
 }
 
-template <int M_REP, int C_REP, int J, int D, bool SCAL>
+template <int M_REP, int C_REP, int J, int D, int SCAL>
 static hipError_t wt_launch2(const WgLeanP& p, int B, hipStream_t st) {
   constexpr int MT = 32 * M_REP, CT = 32 * C_REP;
   auto k = conv_wgrad_tile_kernel<M_REP, C_REP, J, D, SCAL>;
   TDVC_BIG_LDS_ONCE(k); TDVC_TRACE(k);
   dim3 grid(p.ngroups, ((p.R + MT - 1) / MT) * ((p.Cin + CT - 1) / CT), 1);      // wide: ngroups counts (sample, tile) chunk groups
   const size_t lds = (size_t)(MT * WT_AS + CT * WT_XS) * sizeof(float);
-  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
+  const WgLeanP& q = p;
+  hipLaunchKernelGGL(k, grid, dim3(256), lds, st, q);
   return hipGetLastError();
 }
 
@@ -349,7 +414,17 @@ template <int M_REP, int C_REP, int J, int D>
 static hipError_t wt_launch(const WgLeanP& p, int B, hipStream_t st) {
   // aligned long sequences with plain prologues -> float4 prefetch; everything else -> scalar prefetch
   const bool vec = p.vec && p.a.xf.kind <= XF_LRELU && p.x.xf.kind <= XF_LRELU && p.N >= 2 * WT_NTC;
-  return vec ? wt_launch2<M_REP, C_REP, J, D, false>(p, B, st) : wt_launch2<M_REP, C_REP, J, D, true>(p, B, st);
+  if (vec) return wt_launch2<M_REP, C_REP, J, D, 0>(p, B, st);
+  // contiguous-tile staging (kernel, mode 3): one whole short sequence per chunk, full tiles, rows back to back, zero padding, tiles
+  // that start on 16-byte boundaries (D layer 5: 1024 -> 1024, T = 63)
+  constexpr int MT = 32 * M_REP, CT = 32 * C_REP;
+  auto al16 = [](const void* ptr) { return (((uintptr_t)ptr) & 15) == 0; };
+  const bool contig = g_knob[4] == 0 && p.ntiles == 1 && p.N <= WT_NTC && p.x.T == p.N && p.a.T == p.N && !p.reflect &&
+                      p.R % MT == 0 && p.Cin % CT == 0 && (MT * p.N) % 4 == 0 && (CT * p.N) % 4 == 0 && (p.a.bs & 3) == 0 && (p.x.bs & 3) == 0 &&
+                      al16(p.a.p) && al16(p.x.p) && p.lo <= 0 && p.N - p.lo <= WT_XS &&
+                      (p.a.xf.kind <= XF_LRELU || (p.a.xf.kind == XF_MASK_LRELU && al16(p.a.xf.aux) && (p.a.xf.aux_bs & 3) == 0)) &&
+                      p.x.xf.kind <= XF_LRELU;
+  return contig ? wt_launch2<M_REP, C_REP, J, D, 2>(p, B, st) : wt_launch2<M_REP, C_REP, J, D, 1>(p, B, st);
 }
 
 template <int J, int D>
