@@ -582,7 +582,10 @@ __global__ __launch_bounds__(256) void conv_scalar_kernel(const GemmConvP p) {
 // (row tile, 16-channel tile) x (time chunk, batch group); the 4 waves split the time chunk and
 // are summed through LDS; the block writes its partial into a slab (no atomics: deterministic).
 template <int MODE, int M_REP, int J>
-__global__ __launch_bounds__(256, (M_REP * J >= 14 ? 3 : 4)) void conv_wgrad_kernel(const WgradP p, int bpb, int B) {
+#ifndef WGRAD_OCC
+#define WGRAD_OCC 4      // resident blocks per CU asked of the generic weight-grad kernel (A/B: make ab EXTRA=-DWGRAD_OCC=3)
+#endif
+__global__ __launch_bounds__(256, (M_REP * J >= 14 ? 3 : WGRAD_OCC)) void conv_wgrad_kernel(const WgradP p, int bpb, int B) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int MT = 16 * M_REP;
   constexpr int E = M_REP * J * 4;

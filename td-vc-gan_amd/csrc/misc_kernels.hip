@@ -777,10 +777,10 @@ extern "C" int tdvc_l1_bwd(const float* a, const float* b, int64_t n, float weig
 // bwd: da_i = sign(a_i - b_i) * weight_i / n_i * upstream, or da_i = 0 where b_i == NULL.
 static int l1_multi(const tdvc_l1_pair* pairs, int npairs, bool bwd, float* loss_out, const float* upstream, hipStream_t st) {
   if (!pairs || npairs < 0) return tdvc_fail(TDVC_EINVAL, "l1_multi: bad argument");
-  for (int p0 = 0; p0 < npairs; p0 += L1M_MAX) {
+  for (int i = 0; i < npairs;) {                       // batches of up to L1M_MAX live entries
     L1Batch q = {};
     int chunks = 0;
-    for (int i = p0; i < npairs && q.np < L1M_MAX; ++i) {
+    for (; i < npairs && q.np < L1M_MAX; ++i) {
       const tdvc_l1_pair& e = pairs[i];
       if (e.n <= 0) continue;
       if (bwd ? !e.da || (e.b && !e.a) : (!e.a || !e.b)) {
