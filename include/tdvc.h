@@ -179,6 +179,12 @@ int tdvc_film_k3_fwd(const float* emb, int64_t emb_bs, const float* w0, const fl
                      int32_t n_cond, void* stream);
 int tdvc_film_k3_bwd(const float* dk3, const float* emb, int64_t emb_bs, const float* w0, float* demb, float* dw0, float* db0,
                      int32_t B, int32_t n_const, int32_t n_cond, void* stream);
+/* The same for all FiLM blocks of one MRF stage (they share `emb`): nblk <= 16 weight / bias / k3 pointers as HOST arrays (read
+ * before the call returns); the backward writes `demb` already summed over the blocks and accumulates each block's dw0 / db0. */
+int tdvc_film_k3_multi_fwd(const float* emb, int64_t emb_bs, const float* const* w0s, const float* const* b0s, float* const* k3s,
+                           int32_t nblk, int32_t B, int32_t n_const, int32_t n_cond, void* stream);
+int tdvc_film_k3_multi_bwd(const float* const* dk3s, const float* emb, int64_t emb_bs, const float* const* w0s, float* demb,
+                           float* const* dw0s, float* const* db0s, int32_t nblk, int32_t B, int32_t n_const, int32_t n_cond, void* stream);
 
 /* Multi-tensor weight norm (old-style nn.utils.weight_norm, dim=0; model/generator.py:14,
  * util/__init__.py:16-20, model/discriminator.py:11): w[row] = g[row] * v[row] / ||v[row]||, one wave per

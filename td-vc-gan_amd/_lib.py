@@ -80,6 +80,8 @@ SIGNATURES = {
     'tdvc_film_cond0_bwd': (_i, [C.POINTER(FilmCond0BwdArgs), _vp]),
     'tdvc_film_k3_fwd': (_i, [_vp, _i64, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp]),
     'tdvc_film_k3_bwd': (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp]),
+    'tdvc_film_k3_multi_fwd': (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
+    'tdvc_film_k3_multi_bwd': (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),
     'tdvc_film_cond0_bwd_workspace': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     'tdvc_set_force_generic': (None, [_i]),
     'tdvc_debug_force_tile': (None, [_i]),

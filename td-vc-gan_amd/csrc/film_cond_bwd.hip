@@ -281,6 +281,90 @@ __global__ __launch_bounds__(256) void film_k3_bwd_kernel(const float* dk3, cons
   }
 }
 
+// The same two ops for ALL FiLM blocks of one MRF stage (9 blocks read the same embedding): one launch each way instead of
+// nine, and the embedding gradient comes out already summed over the blocks (fixed order: deterministic).
+constexpr int K3M_MAX = 16;
+struct K3Multi { const float* w0[K3M_MAX]; const float* b0[K3M_MAX]; float* k3[K3M_MAX]; const float* dk3[K3M_MAX]; float* dw0[K3M_MAX]; float* db0[K3M_MAX]; int n; };
+
+__global__ __launch_bounds__(256) void film_k3_multi_fwd_kernel(const float* emb, long emb_bs, const K3Multi m, int B, int n_const, int nc) {
+  const int z = blockIdx.z;
+  const int lane = threadIdx.x & 63, c = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (c >= nc) return;
+  const float* w = m.w0[z] + (long)c * nc * 3;
+  float wa[4], wb[4], wc[4];                       // n_const <= 256
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int ci = lane + 64 * i;
+    const bool ok = ci < n_const;
+    wa[i] = ok ? w[ci * 3] : 0.f; wb[i] = ok ? w[ci * 3 + 1] : 0.f; wc[i] = ok ? w[ci * 3 + 2] : 0.f;
+  }
+  const float bias = m.b0[z] ? m.b0[z][c] : 0.f;
+  float* k3 = m.k3[z];
+  const int b_end = min(B, ((int)blockIdx.y + 1) * 4);
+  for (int b = blockIdx.y * 4; b < b_end; ++b) {
+    const float* e = emb + (long)b * emb_bs;
+    float s0 = 0.f, s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      const int ci = lane + 64 * i;
+      const float ev = ci < n_const ? e[ci] : 0.f;
+      s0 += ev * (wb[i] + wc[i]); s1 += ev * ((wa[i] + wb[i]) + wc[i]); s2 += ev * (wa[i] + wb[i]);
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) { s0 += __shfl_xor(s0, o); s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+    if (lane == 0) { float* o3 = k3 + ((long)b * nc + c) * 3; o3[0] = s0 + bias; o3[1] = s1 + bias; o3[2] = s2 + bias; }
+  }
+}
+
+// blocks [0, nA) x grid.y = FiLM block: weight / bias gradients of that block; blocks [nA, ...) (grid.y == 0 only): embedding
+// gradient summed over the FiLM blocks
+__global__ __launch_bounds__(256) void film_k3_multi_bwd_kernel(const float* emb, long emb_bs, const K3Multi m, float* demb, int B, int n_const,
+                                                                int nc, int nA) {
+  if ((int)blockIdx.x < nA) {
+    const int z = blockIdx.y;
+    float* dw0 = m.dw0[z];
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= nc * n_const || !dw0) return;
+    const int c = idx / n_const, ci = idx - c * n_const;
+    const float* dk3 = m.dk3[z];
+    float g0 = 0.f, g1 = 0.f, g2 = 0.f, gb = 0.f;
+    for (int b = 0; b < B; ++b) {
+      const float* d = dk3 + ((long)b * nc + c) * 3;
+      const float d0 = d[0], d1 = d[1], d2 = d[2], ev = emb[(long)b * emb_bs + ci];
+      g0 += ev * (d1 + d2); g1 += ev * ((d0 + d1) + d2); g2 += ev * (d0 + d1); gb += (d0 + d1) + d2;
+    }
+    float* o = dw0 + ((long)c * nc + ci) * 3;
+    o[0] += g0; o[1] += g1; o[2] += g2;
+    if (ci == 0 && m.db0[z]) m.db0[z][c] += gb;
+  } else {
+    if (blockIdx.y != 0 || !demb) return;
+    __shared__ float part[8][32];
+    const int blk = (int)blockIdx.x - nA;
+    const int per_b = (n_const + 31) / 32;
+    const int b = blk / per_b, ci = (blk - b * per_b) * 32 + (threadIdx.x & 31), cg = threadIdx.x >> 5;
+    float a = 0.f;
+    if (ci < n_const) {
+      for (int z = 0; z < m.n; ++z) {
+        const float* dk3 = m.dk3[z]; const float* w0 = m.w0[z];
+        for (int c = cg; c < nc; c += 8) {
+          const float* d = dk3 + ((long)b * nc + c) * 3;
+          const float* w = w0 + ((long)c * nc + ci) * 3;
+          const float d0 = d[0], d1 = d[1], d2 = d[2];
+          a += w[0] * (d1 + d2) + w[1] * ((d0 + d1) + d2) + w[2] * (d0 + d1);
+        }
+      }
+    }
+    part[cg][threadIdx.x & 31] = a;
+    __syncthreads();
+    if (cg == 0 && ci < n_const) {
+      float t = 0.f;
+#pragma unroll
+      for (int g = 0; g < 8; ++g) t += part[g][threadIdx.x];
+      demb[(long)b * n_const + ci] = t;
+    }
+  }
+}
+
 static void cond0_plan(int B, int T, int* ntile, int* tpb, int* nblocks) {
   *ntile = (T + CB_NT - 1) / CB_NT;
   const long nchunks = (long)B * (*ntile);
@@ -340,6 +424,40 @@ extern "C" int tdvc_film_k3_fwd(const float* emb, int64_t emb_bs, const float* w
   if (!emb || !w0 || !k3 || B <= 0 || n_const <= 0 || n_const > 256 || n_cond < n_const) return tdvc_fail(TDVC_EINVAL, "film_k3_fwd: bad arguments");
   hipLaunchKernelGGL(film_k3_fwd_kernel, dim3((n_cond + 3) / 4, (B + 3) / 4), dim3(256), 0, (hipStream_t)stream, emb, (long)emb_bs, w0, b0, k3, B,
                      n_const, n_cond);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+
+extern "C" int tdvc_film_k3_multi_fwd(const float* emb, int64_t emb_bs, const float* const* w0s, const float* const* b0s, float* const* k3s,
+                                      int32_t nblk, int32_t B, int32_t n_const, int32_t n_cond, void* stream) {
+  if (!emb || !w0s || !k3s || nblk < 1 || nblk > K3M_MAX || B <= 0 || n_const <= 0 || n_const > 256 || n_cond < n_const)
+    return tdvc_fail(TDVC_EINVAL, "film_k3_multi_fwd: bad arguments");
+  K3Multi m = {};
+  m.n = nblk;
+  for (int i = 0; i < nblk; ++i) {
+    if (!w0s[i] || !k3s[i]) return tdvc_fail(TDVC_EINVAL, "film_k3_multi_fwd: null pointer");
+    m.w0[i] = w0s[i]; m.b0[i] = b0s ? b0s[i] : nullptr; m.k3[i] = k3s[i];
+  }
+  hipLaunchKernelGGL(film_k3_multi_fwd_kernel, dim3((n_cond + 3) / 4, (B + 3) / 4, nblk), dim3(256), 0, (hipStream_t)stream, emb, (long)emb_bs, m, B,
+                     n_const, n_cond);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
+}
+
+extern "C" int tdvc_film_k3_multi_bwd(const float* const* dk3s, const float* emb, int64_t emb_bs, const float* const* w0s, float* demb,
+                                      float* const* dw0s, float* const* db0s, int32_t nblk, int32_t B, int32_t n_const, int32_t n_cond, void* stream) {
+  if (!dk3s || !emb || !w0s || nblk < 1 || nblk > K3M_MAX || B <= 0 || n_const <= 0 || n_cond < n_const)
+    return tdvc_fail(TDVC_EINVAL, "film_k3_multi_bwd: bad arguments");
+  K3Multi m = {};
+  m.n = nblk;
+  bool any_w = false;
+  for (int i = 0; i < nblk; ++i) {
+    if (!dk3s[i] || !w0s[i]) return tdvc_fail(TDVC_EINVAL, "film_k3_multi_bwd: null pointer");
+    m.dk3[i] = dk3s[i]; m.w0[i] = w0s[i]; m.dw0[i] = dw0s ? dw0s[i] : nullptr; m.db0[i] = (db0s && m.dw0[i]) ? db0s[i] : nullptr;
+    any_w = any_w || m.dw0[i];
+  }
+  const int nA = any_w ? (n_cond * n_const + 255) / 256 : 0, nB = demb ? B * ((n_const + 31) / 32) : 0;
+  if (nA + nB == 0) return TDVC_OK;
+  hipLaunchKernelGGL(film_k3_multi_bwd_kernel, dim3(nA + nB, any_w ? nblk : 1), dim3(256), 0, (hipStream_t)stream, emb, (long)emb_bs, m, demb, B,
+                     n_const, n_cond, nA);
   TDVC_CHECK_LAUNCH(); return TDVC_OK;
 }
 

@@ -188,13 +188,15 @@ class FiLMResnetBlock(nn.Module):
             self.spec_const.slot = s                                             # carries the bias
             self.spec_var.slot = ConvSlot(s.w, 0, s.dw, 0, s.trainable, s.arena, s.wt, s.seg)  # no bias on the time-varying part
 
-    def forward(self, x, c=None, acc=None, scale=1.0):
+    def forward(self, x, c=None, acc=None, scale=1.0, k3=None):
         """c: None (encoder), a dense [B,n_const+n_var,T] conditioning tensor (reference formulation), or a
-        (emb [B,n_const] or emb3 [B,n_const,3], exc [B,n_var,T]) pair for the split formulation."""
+        (emb [B,n_const] or emb3 [B,n_const,3], exc [B,n_var,T]) pair for the split formulation; k3: the embedding part of
+        cond_var.0 when the caller has already computed it for all blocks of the stage (ops.film_k3_multi)."""
         gb = None
         if isinstance(c, tuple):
             emb3, exc = c
-            k3 = ops.film_k3(emb3, self.spec_const) if emb3.dim() == 2 else ops.conv(emb3, self.spec_const)
+            if k3 is None:
+                k3 = ops.film_k3(emb3, self.spec_const) if emb3.dim() == 2 else ops.conv(emb3, self.spec_const)
             if FUSED_COND and exc.shape[2] % 4 == 0:
                 gb = ops.film_cond(exc, k3, self.spec_var, self.cond_var[2].spec)
             else:
@@ -217,9 +219,13 @@ class MRFBlock(nn.Module):
         # x feeds every branch, the conditioning every block: their gradients come back summed in one pass each (ops.fanout)
         nblk = sum(len(br) for br in self.blocks)
         xin = ops.fanout(x, len(self.blocks))
-        cs = [c] * nblk
+        cs, k3s = [c] * nblk, [None] * nblk
         if isinstance(c, tuple):
-            cs = list(zip(ops.fanout(c[0], nblk), ops.fanout(c[1], nblk)))
+            if c[0].dim() == 2 and nblk <= 16:      # the embedding part of every block's cond_var.0 in one launch each way
+                k3s = ops.film_k3_multi(c[0], [blk.spec_const for br in self.blocks for blk in br])
+                cs = [(c[0], e) for e in ops.fanout(c[1], nblk)]
+            else:
+                cs = list(zip(ops.fanout(c[0], nblk), ops.fanout(c[1], nblk)))
         elif c is not None:
             cs = list(ops.fanout(c, nblk))
         i = 0
@@ -227,7 +233,7 @@ class MRFBlock(nn.Module):
             xs = xin[bi]
             for j, blk in enumerate(branch):
                 last = j == len(branch) - 1
-                xs = blk(xs, cs[i], acc if last else None, s if last else 1.0)
+                xs = blk(xs, cs[i], acc if last else None, s if last else 1.0, k3=k3s[i])
                 i += 1
             acc = xs
         return acc

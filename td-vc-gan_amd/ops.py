@@ -365,6 +365,51 @@ def film_k3(emb, spec_const):
     return FilmK3Fn.apply(emb, _token(spec_const), spec_const)
 
 
+class FilmK3MultiFn(Function):
+    """FilmK3Fn for all FiLM blocks of one MRF stage at once (they read the same embedding): one launch forward, one backward
+    (tdvc_film_k3_multi_*), and the embedding gradient comes back already summed over the blocks."""
+
+    @staticmethod
+    def forward(ctx, emb, token, *specs):
+        emb = emb.contiguous()
+        B, n_const = emb.shape
+        nc = specs[0].cout
+        n = len(specs)
+        k3s = [torch.empty((B, nc, 3), dtype=torch.float32, device=emb.device) for _ in specs]
+        w0 = (C.c_void_p * n)(*[sp.slot.w for sp in specs])
+        b0 = (C.c_void_p * n)(*[(sp.slot.b or None) for sp in specs])
+        out = (C.c_void_p * n)(*[t.data_ptr() for t in k3s])
+        L.check(L.lib().tdvc_film_k3_multi_fwd(emb.data_ptr(), emb.stride(0), w0, b0, out, n, B, n_const, nc, _stream(emb)))
+        ctx.specs = specs
+        ctx.save_for_backward(emb)
+        return tuple(k3s)
+
+    @staticmethod
+    def backward(ctx, *dk3s):
+        (emb,) = ctx.saved_tensors
+        specs = ctx.specs
+        B, n_const = emb.shape
+        n = len(specs)
+        dk = [(g.contiguous() if g is not None else torch.zeros((B, specs[0].cout, 3), dtype=torch.float32, device=emb.device)) for g in dk3s]
+        want = [sp.slot.trainable and (sp.slot.arena is None or sp.slot.arena.wgrad_enabled) for sp in specs]
+        demb = torch.empty_like(emb) if ctx.needs_input_grad[0] else None
+        pd = (C.c_void_p * n)(*[t.data_ptr() for t in dk])
+        w0 = (C.c_void_p * n)(*[sp.slot.w for sp in specs])
+        dw = (C.c_void_p * n)(*[(sp.slot.dw if w_ else None) for sp, w_ in zip(specs, want)])
+        db = (C.c_void_p * n)(*[((sp.slot.db or None) if w_ else None) for sp, w_ in zip(specs, want)])
+        L.check(L.lib().tdvc_film_k3_multi_bwd(pd, emb.data_ptr(), emb.stride(0), w0, demb.data_ptr() if demb is not None else None, dw, db,
+                                               n, B, n_const, specs[0].cout, _stream(emb)))
+        for sp, w_ in zip(specs, want):
+            if w_ and sp.slot.arena is not None:
+                sp.slot.arena.note_grad(sp.slot)
+        return (demb, None) + (None,) * n
+
+
+def film_k3_multi(emb, specs):
+    """k3 of every spec in `specs` (<= 16, same shapes) from one embedding; returns a tuple of [B, nc, 3] tensors."""
+    return FilmK3MultiFn.apply(emb, _token(*specs), *specs)
+
+
 def film_cond(exc, k3, spec_var, spec2):
     return FilmCondFn.apply(exc, k3, _token(spec_var, spec2), spec_var, spec2)
 

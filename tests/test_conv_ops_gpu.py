@@ -315,3 +315,39 @@ def test_l1_multi(dev):
     for x, y, d, wi in zip(a, b, da, w):
         assert torch.allclose(d, torch.sign(x - y) * (wi * 1.7 / x.numel()), rtol=1e-6, atol=0)
     assert float(zero.abs().max()) == 0.0
+
+
+def test_film_k3_multi_matches_single(dev):
+    """ops.film_k3_multi (all FiLM blocks of a stage in one launch each way) against the per-block FilmK3Fn: outputs, weight /
+    bias gradients per block, and the embedding gradient summed over the blocks."""
+    ops, L, arena = _mods()
+    torch.manual_seed(3)
+    B, n_const, nc, nblk = 5, 128, 136, 9
+    ws = [(torch.randn(nc, nc, 3, device=dev) / (nc * 3) ** 0.5) for _ in range(nblk)]
+    bs = [torch.randn(nc, device=dev) * 0.1 for _ in range(nblk)]
+    cots = [torch.randn(B, nc, 3, device=dev) for _ in range(nblk)]
+    emb = torch.randn(B, n_const, device=dev)
+
+    def run(multi):
+        dws, dbs = [torch.zeros_like(w) for w in ws], [torch.zeros_like(b) for b in bs]
+        specs = []
+        for w, b, dw, db in zip(ws, bs, dws, dbs):
+            sp = ops.ConvSpec(n_const, nc, 3, 1, 1, 1, 1, False, w_cin=nc, w_cin_off=0)
+            sp.slot = arena.ConvSlot(w.data_ptr(), b.data_ptr(), dw.data_ptr(), db.data_ptr(), True, None, 0)
+            specs.append(sp)
+        e = emb.clone().requires_grad_(True)
+        k3s = ops.film_k3_multi(e, specs) if multi else [ops.film_k3(e, sp) for sp in specs]
+        sum((k * c).sum() for k, c in zip(k3s, cots)).backward()
+        torch.cuda.synchronize()
+        return [k.detach() for k in k3s], e.grad, dws, dbs
+    k_m, de_m, dw_m, db_m = run(True)
+    k_s, de_s, dw_s, db_s = run(False)
+    for a, b_ in zip(k_m, k_s):
+        assert torch.equal(a, b_)
+    assert rel_l2(de_m, de_s) < 1e-6
+    for a, b_ in zip(dw_m + db_m, dw_s + db_s):
+        assert torch.equal(a, b_)
+    # and the forward against plain torch: cond_var.0 on the constant embedding channels as a length-3 signal
+    x3 = emb[:, :, None].expand(B, n_const, 3).double().cpu()
+    ref = torch.nn.functional.conv1d(x3, ws[0][:, :n_const].double().cpu(), bs[0].double().cpu(), padding=1)
+    assert rel_l2(k_m[0], ref) < 1e-6
