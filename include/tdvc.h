@@ -137,6 +137,23 @@ void tdvc_debug_lds_cap(int bytes);   /* tuning knob: LDS bytes per block the le
 void tdvc_debug_trace(int on);
 size_t tdvc_debug_trace_dump(char* buf, size_t cap);
 
+/* Fused forward of one FiLM residual block (model/generator.py:96-111), narrow long-sequence case (C == 16, T % 4 == 0, T >= 512,
+ * reflect padding (K-1)*dilation/2, 16-byte aligned operands; TDVC_EUNSUPPORTED otherwise -> run the two tdvc_conv_fwd calls):
+ *   h = conv_kd(LeakyReLU(x)) + b1 (stored for the backward pass);  y = scale * (conv_1x1(LeakyReLU(h*(1+gamma)+beta)) + b2 + x) + add
+ * gb = [gamma; beta] [B][2C][T] or NULL (no FiLM: LeakyReLU(h)); add = MRF running sum or NULL. Bit-identical to the two-launch path. */
+typedef struct {
+  int32_t B, C, T, K, dilation;
+  const float* x; int64_t x_bs;
+  const float* w1; const float* b1;        /* dilated conv [C][C][K], bias or NULL */
+  float* h; int64_t h_bs;
+  const float* gb; int64_t gb_bs;
+  const float* w2; const float* b2;        /* 1x1 conv [C][C][1], bias or NULL */
+  const float* add; int64_t add_bs;
+  float scale, slope;
+  float* y; int64_t y_bs;
+} tdvc_film_block_args;
+int tdvc_film_block_fwd(const tdvc_film_block_args* a, void* stream);
+
 /* Fused FiLM conditioning forward (model/generator.py:86-92, 103): gb = cond_var.2(LeakyReLU(cond_var.0(c))) with
  * c = [speaker embedding (n_cond-n_var channels, constant in time) ; excitation (n_var channels)]. The time-constant part
  * enters as k3 [B][n_cond][3] (= cond_var.0 restricted to the embedding channels, evaluated on a length-3 signal, bias

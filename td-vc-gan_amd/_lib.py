@@ -32,6 +32,13 @@ class ConvFwdArgs(C.Structure):
                 ('y_bs', C.c_int64), ('bias3', C.c_void_p), ('sign_bits', C.c_void_p), ('sign_bits_bs', C.c_int64)]
 
 
+class FilmBlockArgs(C.Structure):
+    _fields_ = [('B', C.c_int32), ('C', C.c_int32), ('T', C.c_int32), ('K', C.c_int32), ('dilation', C.c_int32),
+                ('x', C.c_void_p), ('x_bs', C.c_int64), ('w1', C.c_void_p), ('b1', C.c_void_p), ('h', C.c_void_p), ('h_bs', C.c_int64),
+                ('gb', C.c_void_p), ('gb_bs', C.c_int64), ('w2', C.c_void_p), ('b2', C.c_void_p), ('add', C.c_void_p), ('add_bs', C.c_int64),
+                ('scale', C.c_float), ('slope', C.c_float), ('y', C.c_void_p), ('y_bs', C.c_int64)]
+
+
 class FilmCondArgs(C.Structure):
     _fields_ = [('B', C.c_int32), ('T', C.c_int32), ('n_cond', C.c_int32), ('n_var', C.c_int32), ('C2', C.c_int32),
                 ('exc', C.c_void_p), ('exc_bs', C.c_int64), ('w0', C.c_void_p), ('k3', C.c_void_p),
@@ -64,6 +71,7 @@ class ConvWgradArgs(C.Structure):
                 ('workspace_bytes', C.c_size_t)]
 
 
+EUNSUPPORTED = -4      # tdvc_status TDVC_EUNSUPPORTED
 XF_NONE, XF_LRELU, XF_FILM_LRELU, XF_MASK_LRELU, XF_MASK_TANH = range(5)
 CONV, CONV_TRANSPOSE = 0, 1
 POST_NONE, POST_LRELU, POST_TANH = 0, 1, 2
@@ -78,6 +86,7 @@ SIGNATURES = {
     'tdvc_conv_wgrad_workspace': (C.c_size_t, [C.POINTER(ConvDesc)]),
     'tdvc_film_cond_fwd': (_i, [C.POINTER(FilmCondArgs), _vp]),
     'tdvc_film_cond0_bwd': (_i, [C.POINTER(FilmCond0BwdArgs), _vp]),
+    'tdvc_film_block_fwd': (_i, [_vp, _vp]),
     'tdvc_film_k3_fwd': (_i, [_vp, _i64, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp]),
     'tdvc_film_k3_bwd': (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp]),
     'tdvc_film_k3_multi_fwd': (_i, [_vp, _i64, _vp, _vp, _vp, _i, _i, _i, _i, _vp]),

@@ -1,0 +1,239 @@
+// Fused forward of one FiLM residual block (model/generator.py:96-111) for the narrow, long-sequence end of the trunk
+// (16 channels at T = 16000): the dilated Conv1d and its consumers in ONE launch,
+//     h   = conv_kd(LeakyReLU(x)) + b1                       (reflect padding; h is stored: the backward pass reads it)
+//     out = scale * (conv_1x1(LeakyReLU(h * (1 + gamma) + beta)) + b2 + x) + acc
+// instead of two launches that each pay the fixed cost of a short HBM-bound kernel (~8 us of a 22 us launch) and move h
+// through HBM twice. Same arithmetic, in the same order, as conv_lean_kernel<1,4,1,4,ACT,FWD> followed by
+// conv_lean_kernel<1,4,1,4,FILM,FWD>: the results are bit-identical to the two-launch path (tests/test_conv_ops_gpu.py).
+//
+// Block = 16 channels x 256 time steps of one sample, 4 waves x 64 columns. After the dilated conv's MFMAs every wave holds
+// its h tile in the accumulator layout (lane = channel, 4 consecutive steps); FiLM + LeakyReLU are applied there, the result
+// is transposed through LDS (the input tile's space, after a block barrier) into the [channel][step] layout the 1x1 conv's
+// fragment reads expect, and the second product (K = 16: 4 MFMA steps) runs on it.
+#include "conv_common.h"
+#include "film_block.h"
+
+namespace tdvc {
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+constexpr int FB_NT = 256, FB_HS = 80;      // time tile; row stride of a wave's h2 patch (16 mod 32: conflict-free fragment reads)
+constexpr int FB_XVP = 8, FB_WVP = 4;       // max row-walk passes of the input tile / the conv weight tile
+
+template <bool FILM>
+__global__ __launch_bounds__(256, 5) void film_block_fwd_kernel(const FilmBlockP p) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  constexpr int N_REP = 4;
+  float* xs = smem;                               // [16][XS] input tile, later the 4 waves' h2 patches [16][FB_HS]
+  float* ws = smem + p.xs_floats;                 // [16][WS] dilated-conv weights
+  float* w2s = ws + p.wnp * p.wrp * p.WS;         // [16][18] 1x1 weights, row = output channel (behind every row the weight walk stages)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int ln = lane & 15, kq = lane >> 4;
+  const int n0 = blockIdx.x * FB_NT, b = blockIdx.z;
+  const int wcol0 = wave * 16 * N_REP;
+  const int q0 = n0 + p.lo;
+  const int jc = p.K * 16;
+
+  // ---- stage: input tile (LeakyReLU on the way in), conv weights, 1x1 weights
+  const RowWalk xw = make_walk(tid, p.span >> 2, p.xrp, p.T, p.XS, q0, p.T);
+  const RowWalk ww = make_walk(tid, jc >> 2, p.wrp, jc, p.WS, 0, 1 << 30);
+  RegTile<FB_XVP> xr;
+  RegTile<FB_WVP> wr;
+  const float* xrow0 = p.x + (long)b * p.x_bs;
+  {
+    const srd_t rx = make_srd(xrow0, 16 * p.T * 4);
+    walk_issue<FB_XVP>(xr, rx, xw, p.xnp);
+    const srd_t rw = make_srd(p.w1, 16 * jc * 4);
+    walk_issue<FB_WVP>(wr, rw, ww, p.wnp);
+  }
+  const float w2v = p.w2[tid];                     // 256 threads = 16 x 16 weights
+  walk_commit_act<FB_XVP>(xr, xw, p.xnp, xs, p.slope, 1.f, false);
+  if (q0 < 0 || q0 + p.span > p.T) {               // reflect halo of the sample's first / last tile
+    const int nl = q0 < 0 ? -q0 : 0;
+    const int rfirst = p.T - q0;
+    const int nr = rfirst < p.span ? p.span - rfirst : 0;
+    const int nh = nl + nr;
+    __syncthreads();
+    const float inv = 1.0f / (float)nh;
+    for (int e = tid; e < 16 * nh; e += 256) {
+      const int r = (int)(((float)e + 0.5f) * inv);
+      const int hh = e - r * nh;
+      const int i = hh < nl ? hh : rfirst + (hh - nl);
+      int q = q0 + i;
+      q = q < 0 ? -q : 2 * (p.T - 1) - q;
+      float v = (q >= 0 && q < p.T) ? xrow0[(long)r * p.T + q] : 0.f;
+      v = v > 0.f ? v : v * p.slope;
+      xs[r * p.XS + i] = v;
+    }
+  }
+  walk_commit_w<FB_WVP>(wr, ww, p.wnp, ws);
+  w2s[(tid >> 4) * 18 + (tid & 15)] = w2v;
+  __syncthreads();
+
+  // ---- dilated conv: D[t][co] += X'[t][k] * W1[k][co], one step = 4 channels of one tap
+  f32x4 acc[N_REP];
+#pragma unroll
+  for (int n = 0; n < N_REP; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  {
+    const float* w_lane = ws + ln * p.WS + kq * p.K;
+    const float* x_lane = xs + kq * p.XS + wcol0 + ln + p.i0;
+    const int nsteps = p.K * 4;
+    int sj = 0, scs = 0, woff = 0, xoff = 0;
+    auto advance = [&]() {
+      if (++scs == 4) { scs = 0; ++sj; woff = sj; xoff = sj * p.d; }
+      else { woff += 4 * p.K; xoff += 4 * p.XS; }
+    };
+    float wv[2], xv[2][N_REP];
+    auto load_frag = [&](int buf) {
+      wv[buf] = w_lane[woff];
+      const float* xp = x_lane + xoff;
+#pragma unroll
+      for (int n = 0; n < N_REP; ++n) xv[buf][n] = xp[n * 16];
+    };
+    auto mma = [&](int buf) {
+#pragma unroll
+      for (int n = 0; n < N_REP; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[buf][n], wv[buf], acc[n], 0, 0, 0);
+    };
+    load_frag(0);
+    int s = 0;
+    for (; s + 2 <= nsteps; s += 2) {
+      advance(); load_frag(1);
+      mma(0);
+      if (s + 2 < nsteps) { advance(); load_frag(0); }
+      mma(1);
+    }
+    if (s < nsteps) mma(0);
+  }
+
+  // ---- h = conv + b1 (stored), h2 = LeakyReLU(h * (1 + gamma) + beta) into the wave's LDS patch, [channel][step]
+  __syncthreads();                                  // every wave is done reading the input tile
+  float* hp = xs + wave * (16 * FB_HS);
+  {
+    const int co = ln;
+    const float b1 = p.b1 ? p.b1[co] : 0.f;
+    const long ro = (long)co * p.T;
+#pragma unroll
+    for (int n = 0; n < N_REP; ++n) {
+      const int t0 = n0 + wcol0 + n * 16 + kq * 4;
+      f32x4 v = acc[n];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] += b1;
+      f32x4 h2 = (f32x4){0.f, 0.f, 0.f, 0.f};
+      if (t0 < p.T) {
+        *reinterpret_cast<f32x4*>(p.h + (long)b * p.h_bs + ro + t0) = v;
+        if (FILM) {
+          const float* gp = p.gb + (long)b * p.gb_bs + ro + t0;
+          const f32x4 ga = *reinterpret_cast<const f32x4*>(gp);
+          const f32x4 be = *reinterpret_cast<const f32x4*>(gp + (long)16 * p.T);
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { const float u = v[q] * (1.f + ga[q]) + be[q]; h2[q] = fmaxf(u, u * p.slope); }
+        } else {
+#pragma unroll
+          for (int q = 0; q < 4; ++q) h2[q] = fmaxf(v[q], v[q] * p.slope);
+        }
+      }
+      *reinterpret_cast<f32x4*>(hp + co * FB_HS + n * 16 + kq * 4) = h2;
+    }
+  }
+  // wave-private exchange through LDS: DS operations of one wave execute in order; the fences keep the compiler from moving
+  // the fragment reads (other lanes' data) above the writes
+  __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+
+  // ---- 1x1 conv: D2[t][co2] += H2[t][k] * W2[k][co2], K = 16 channels = 4 steps
+  f32x4 acc2[N_REP];
+#pragma unroll
+  for (int n = 0; n < N_REP; ++n) acc2[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int cs = 0; cs < 4; ++cs) {
+    const float wv2 = w2s[ln * 18 + cs * 4 + kq];
+#pragma unroll
+    for (int n = 0; n < N_REP; ++n) {
+      const float xv2 = hp[(cs * 4 + kq) * FB_HS + n * 16 + ln];
+      acc2[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv2, wv2, acc2[n], 0, 0, 0);
+    }
+  }
+
+  // ---- out = scale * (D2 + b2 + x) + acc
+  {
+    const int co = ln;
+    const float b2 = p.b2 ? p.b2[co] : 0.f;
+    const long ro = (long)co * p.T;
+#pragma unroll
+    for (int n = 0; n < N_REP; ++n) {
+      const int t0 = n0 + wcol0 + n * 16 + kq * 4;
+      if (t0 >= p.T) continue;
+      const long oi = ro + t0;
+      f32x4 v = acc2[n];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[q] += b2;
+      const f32x4 r = *reinterpret_cast<const f32x4*>(p.x + (long)b * p.x_bs + oi);
+      v += r;
+      v *= p.scale;
+      if (p.add) { const f32x4 a4 = *reinterpret_cast<const f32x4*>(p.add + (long)b * p.add_bs + oi); v += a4 * 1.f; }
+      *reinterpret_cast<f32x4*>(p.y + (long)b * p.y_bs + oi) = v;
+    }
+  }
+}
+
+static inline void fb_walk_geometry(int rows, int nvec, int* rp, int* np) {
+  *rp = nvec <= 256 ? 256 / nvec : 0;
+  if (*rp > rows) *rp = rows;
+  *np = *rp ? (rows + *rp - 1) / *rp : 1 << 20;
+}
+
+// hipErrorNotSupported: outside the fused kernel's contract (the caller runs the two-launch path).
+hipError_t launch_film_block_fwd(FilmBlockP p, int B, hipStream_t st) {
+  if (p.T < 2 * FB_NT || (p.T & 3) || p.K < 1 || p.K > 15 || p.d < 1) return hipErrorNotSupported;
+  const int pad = (p.K - 1) * p.d / 2;
+  if (2 * pad != (p.K - 1) * p.d || pad >= p.T) return hipErrorNotSupported;
+  const int first = -pad;
+  const int lo = -(((pad) + 3) / 4 * 4);
+  const int hi = (p.K - 1) * p.d - pad;
+  p.lo = lo; p.i0 = first - lo;
+  p.span = ((FB_NT + hi - lo) + 3) / 4 * 4;
+  p.XS = ((p.span + 15) / 32) * 32 + 16;
+  p.WS = p.K * 16 + 2;
+  fb_walk_geometry(16, p.span / 4, &p.xrp, &p.xnp);
+  fb_walk_geometry(16, p.K * 16 / 4, &p.wrp, &p.wnp);
+  if (p.xnp > FB_XVP || p.wnp > FB_WVP) return hipErrorNotSupported;
+  int xs_floats = p.xnp * p.xrp * p.XS;                      // the row walk may stage a few rows past 16
+  if (xs_floats < 4 * 16 * FB_HS) xs_floats = 4 * 16 * FB_HS; // ... and the same space later holds the 4 waves' h2 patches
+  p.xs_floats = xs_floats;
+  const size_t lds = (size_t)(xs_floats + p.wnp * p.wrp * p.WS + 16 * 18) * sizeof(float);
+  if (p.wnp * p.wrp < 16) return hipErrorNotSupported;
+  dim3 grid((p.T + FB_NT - 1) / FB_NT, 1, B);
+  if (p.gb) {
+    auto k = film_block_fwd_kernel<true>;
+    TDVC_BIG_LDS_ONCE(k); TDVC_TRACE(k);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
+  } else {
+    auto k = film_block_fwd_kernel<false>;
+    TDVC_BIG_LDS_ONCE(k); TDVC_TRACE(k);
+    hipLaunchKernelGGL(k, grid, dim3(256), lds, st, p);
+  }
+  return hipGetLastError();
+}
+
+}  // namespace tdvc
+
+using namespace tdvc;
+#include "../../include/tdvc.h"
+#include "api_util.h"
+
+extern "C" int tdvc_film_block_fwd(const tdvc_film_block_args* a, void* stream) {
+  if (!a || !a->x || !a->w1 || !a->h || !a->w2 || !a->y) return tdvc_fail(TDVC_EINVAL, "film_block_fwd: null pointer");
+  if (a->B <= 0 || a->T <= 0 || a->K <= 0 || a->dilation <= 0) return tdvc_fail(TDVC_EINVAL, "film_block_fwd: bad shape");
+  auto ok = [](const void* ptr, int64_t bs) { return !ptr || ((((uintptr_t)ptr) & 15) == 0 && (bs & 3) == 0 && bs < (1LL << 31)); };
+  if (a->C != 16 || !ok(a->x, a->x_bs) || !ok(a->h, a->h_bs) || !ok(a->gb, a->gb_bs) || !ok(a->add, a->add_bs) || !ok(a->y, a->y_bs) ||
+      !ok(a->w1, 0) || !ok(a->w2, 0))
+    return tdvc_fail(TDVC_EUNSUPPORTED, "film_block_fwd: needs 16 channels and 16-byte aligned operands");
+  if (g_force_tile >= 0) return tdvc_fail(TDVC_EUNSUPPORTED, "film_block_fwd: a lean tile is pinned (test-only tdvc_debug_force_tile)");
+  FilmBlockP p = {};
+  p.x = a->x; p.w1 = a->w1; p.b1 = a->b1; p.h = a->h; p.gb = a->gb; p.w2 = a->w2; p.b2 = a->b2; p.add = a->add; p.y = a->y;
+  p.x_bs = (int)a->x_bs; p.h_bs = (int)a->h_bs; p.gb_bs = (int)a->gb_bs; p.add_bs = (int)a->add_bs; p.y_bs = (int)a->y_bs;
+  p.T = a->T; p.K = a->K; p.d = a->dilation; p.slope = a->slope; p.scale = a->scale == 0.f ? 1.f : a->scale;
+  const hipError_t e = launch_film_block_fwd(p, a->B, (hipStream_t)stream);
+  if (e == hipErrorNotSupported) return tdvc_fail(TDVC_EUNSUPPORTED, "film_block_fwd: shape outside the fused kernel's contract");
+  return e == hipSuccess ? TDVC_OK : tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));
+}

@@ -233,13 +233,29 @@ class FilmBlockFn(Function):
     @staticmethod
     def forward(ctx, x, gb, acc, token, conv_spec, pos_spec, scale):
         x = x.contiguous()
-        h = conv_fwd_raw(conv_spec, x, _xf(L.XF_LRELU))
         if gb is not None:
             gb = gb.contiguous()
-            xf2 = _xf(L.XF_FILM_LRELU, aux=gb)
-        else:
-            xf2 = _xf(L.XF_LRELU)
-        out = conv_fwd_raw(pos_spec, h, xf2, res=x, add=acc, out_scale=scale)
+        h = out = None
+        cs, ps = conv_spec, pos_spec
+        if (FUSED_FILM_BLOCK and cs.cin == 16 and cs.cout == 16 and ps.cin == 16 and ps.cout == 16 and ps.k == 1 and cs.reflect and cs.stride == 1 and
+                cs.groups == 1 and 2 * cs.pad == (cs.k - 1) * cs.dil and x.shape[2] % 4 == 0 and x.shape[2] >= 512):
+            # narrow long-sequence blocks: the dilated conv, FiLM, the 1x1 conv and the residual in one launch (film_block.hip)
+            B, _, T = x.shape
+            h, out = torch.empty_like(x), torch.empty_like(x)
+            accc = acc.contiguous() if acc is not None else None
+            a = L.FilmBlockArgs(B, 16, T, cs.k, cs.dil, x.data_ptr(), _bs(x), cs.slot.w, cs.slot.b or None, h.data_ptr(), _bs(h),
+                                gb.data_ptr() if gb is not None else None, _bs(gb) if gb is not None else 0, ps.slot.w, ps.slot.b or None,
+                                accc.data_ptr() if accc is not None else None, _bs(accc) if accc is not None else 0, scale, SLOPE,
+                                out.data_ptr(), _bs(out))
+            rc = L.lib().tdvc_film_block_fwd(C.byref(a), _stream(x))
+            if rc == L.EUNSUPPORTED:
+                h = out = None
+            else:
+                L.check(rc)
+        if out is None:
+            h = conv_fwd_raw(conv_spec, x, _xf(L.XF_LRELU))
+            xf2 = _xf(L.XF_FILM_LRELU, aux=gb) if gb is not None else _xf(L.XF_LRELU)
+            out = conv_fwd_raw(pos_spec, h, xf2, res=x, add=acc, out_scale=scale)
         ctx.cs, ctx.ps, ctx.scale = conv_spec, pos_spec, scale
         ctx.has_gb, ctx.has_acc = gb is not None, acc is not None
         ctx.save_for_backward(x, h, gb)
@@ -265,6 +281,7 @@ class FilmBlockFn(Function):
         return dx, dgb, (d_out if ctx.has_acc else None), None, None, None, None
 
 
+FUSED_FILM_BLOCK = os.environ.get('TDVC_FUSED_FILM_BLOCK', '1') == '1'   # one-launch FiLM block forward at 16 channels (A/B switch)
 FUSED_COND_FWD = os.environ.get('TDVC_FUSED_COND_FWD', '0') == '1'     # single-launch conditioning forward (tdvc_film_cond_fwd)
 SIGN_BIT_MASKS = os.environ.get('TDVC_SIGN_BIT_MASKS', '1') == '1'     # cond_var.2 input-grad reads 1-bit LeakyReLU masks (A/B switch)
 

@@ -6,6 +6,8 @@ import pytest
 import torch
 import torch.nn.functional as F
 
+from common import traced
+
 from conftest import rel_l2
 
 pytestmark = pytest.mark.gpu
@@ -351,3 +353,41 @@ def test_film_k3_multi_matches_single(dev):
     x3 = emb[:, :, None].expand(B, n_const, 3).double().cpu()
     ref = torch.nn.functional.conv1d(x3, ws[0][:, :n_const].double().cpu(), bs[0].double().cpu(), padding=1)
     assert rel_l2(k_m[0], ref) < 1e-6
+
+
+@pytest.mark.parametrize('cfg', [(3, 1, 1040, True, True), (7, 3, 16000, True, False), (11, 5, 2052, False, True), (3, 5, 516, True, False)],
+                         ids=['k3d1_T1040', 'k7d3_T16000', 'k11d5_T2052_nofilm', 'k3d5_T516'])
+def test_fused_film_block_forward_is_bit_identical(cfg, dev):
+    """tdvc_film_block_fwd (dilated conv + FiLM + 1x1 conv + residual in one launch, 16 channels) against the two-launch path:
+    h and out must be bit-identical (same arithmetic in the same order), over ragged time tiles, with / without FiLM and MRF sum."""
+    ops, L, arena = _mods()
+    k, d, T, film, with_acc = cfg
+    torch.manual_seed(k * 100 + d)
+    B, Cc = 3, 16
+    w1 = (torch.randn(Cc, Cc, k) / (Cc * k) ** 0.5).to(dev); b1 = (torch.randn(Cc) * 0.1).to(dev)
+    w2 = (torch.randn(Cc, Cc, 1) / Cc ** 0.5).to(dev); b2 = (torch.randn(Cc) * 0.1).to(dev)
+    cs = ops.ConvSpec(Cc, Cc, k, 1, (k - 1) * d // 2, d, 1, True)
+    cs.slot = arena.ConvSlot(w1.data_ptr(), b1.data_ptr(), 0, 0, False, None, 0)
+    ps = ops.ConvSpec(Cc, Cc, 1)
+    ps.slot = arena.ConvSlot(w2.data_ptr(), b2.data_ptr(), 0, 0, False, None, 0)
+    x0 = torch.randn(B, Cc, T, device=dev)
+    gb0 = torch.randn(B, 2 * Cc, T, device=dev) * 0.5 if film else None
+    acc = torch.randn(B, Cc, T, device=dev) if with_acc else None
+    cot = torch.randn(B, Cc, T, device=dev)
+    outs = {}
+    for fused in (True, False):
+        old = ops.FUSED_FILM_BLOCK
+        ops.FUSED_FILM_BLOCK = fused
+        x = x0.clone().requires_grad_(True)
+        gb = gb0.clone().requires_grad_(True) if film else None
+        try:
+            with traced() as tr:
+                y = ops.FilmBlockFn.apply(x, gb, acc, None, cs, ps, 1.0 / 3)
+                y.backward(cot)      # reads the stored h: a wrong h shows up in both gradients
+        finally:
+            ops.FUSED_FILM_BLOCK = old
+        assert any(n.startswith('film_block_fwd_kernel') for n in tr.names) == fused, sorted(tr.names)
+        outs[fused] = (y.detach().clone(), x.grad.clone(), gb.grad.clone() if film else None)
+    for a_, b_ in zip(outs[True], outs[False]):
+        if a_ is not None:
+            assert torch.equal(a_, b_), float((a_ - b_).abs().max())
