@@ -1,7 +1,9 @@
 """Per-step kernel-time breakdown from a rocprofv3 --kernel-trace CSV of bench.py (diagnostic tool)."""
 import collections, csv, glob, re, sys
 d = sys.argv[1]
-rows = list(csv.DictReader(open(glob.glob(f'{d}/*/*_kernel_trace.csv')[0])))
+f = glob.glob(f'{d}/*/*_kernel_trace.csv*')[0]
+import gzip, io
+rows = list(csv.DictReader(io.TextIOWrapper(gzip.open(f)) if f.endswith('.gz') else open(f)))
 rows.sort(key=lambda r: int(r['Start_Timestamp']))
 ad = [i for i, r in enumerate(rows) if 'adamw' in r['Kernel_Name']]
 lo, hi = ad[1] + 1, ad[-1] + 1

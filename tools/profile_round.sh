@@ -13,3 +13,6 @@ for pass in "fetch FETCH_SIZE" "write WRITE_SIZE" "sq SQ_VALU_MFMA_BUSY_CYCLES S
 done
 cd $R && python3 tools/pmc_traffic.py $OUT/pmc_manifest_fetch.json $OUT/pmc_${TAG}_fetch $OUT/pmc_${TAG}_write $OUT/pmc_${TAG}_sq > $OUT/pmc_$TAG.txt 2>&1
 tail -5 $OUT/pmc_$TAG.txt
+# gpurun copies at most 64 MiB back: keep the summaries, compress the step trace, drop the raw counter dumps
+gzip -f $OUT/prof_$TAG/*/*_kernel_trace.csv 2>/dev/null
+rm -rf $OUT/pmc_${TAG}_fetch $OUT/pmc_${TAG}_write $OUT/pmc_${TAG}_sq
