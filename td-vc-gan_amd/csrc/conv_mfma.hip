@@ -720,7 +720,27 @@ __global__ __launch_bounds__(256, (M_REP * J >= 14 ? 3 : WGRAD_OCC)) void conv_w
 __global__ __launch_bounds__(256) void conv_bias_grad_kernel(const Opnd a, int N, int Ctot, float* dbias) {
   const int ch = blockIdx.x, b = blockIdx.y;
   float s = 0.f;
-  for (int n = threadIdx.x; n < N; n += 256) s += fetch_opnd(a, b, ch, n, 0, Ctot);
+  const float* row = a.p + (long)b * a.bs + (long)ch * a.T;
+  const float* mrow = a.xf.aux ? a.xf.aux + (long)b * a.xf.aux_bs + (long)ch * a.T : nullptr;
+  const int kind = a.xf.kind;
+  if ((N & 3) == 0 && N == a.T && (((uintptr_t)row) & 15) == 0 && (kind <= XF_LRELU || (kind == XF_MASK_LRELU && (((uintptr_t)mrow) & 15) == 0))) {
+    // aligned rows, plain / LeakyReLU / LeakyReLU-mask prologue: float4 loads (block-uniform choice)
+    const float sl = a.xf.slope, sc = a.xf.scale;
+    for (int n = threadIdx.x * 4; n < N; n += 1024) {
+      f32x4_t v = *reinterpret_cast<const f32x4_t*>(row + n);
+      if (kind == XF_LRELU) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = lrelu_f(v[q], sl);
+      } else if (kind == XF_MASK_LRELU) {
+        const f32x4_t m = *reinterpret_cast<const f32x4_t*>(mrow + n);
+#pragma unroll
+        for (int q = 0; q < 4; ++q) v[q] = m[q] > 0.f ? v[q] : v[q] * sl;
+      }
+      s += ((v[0] + v[1]) + (v[2] + v[3])) * sc;
+    }
+  } else {
+    for (int n = threadIdx.x; n < N; n += 256) s += fetch_opnd(a, b, ch, n, 0, Ctot);
+  }
   __shared__ float sh[4];
   for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
   if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = s;
