@@ -8,8 +8,11 @@
 //
 // Block = 16 channels x 256 time steps of one sample, 4 waves x 64 columns. After the dilated conv's MFMAs every wave holds
 // its h tile in the accumulator layout (lane = channel, 4 consecutive steps); FiLM + LeakyReLU are applied there, the result
-// is transposed through LDS (the input tile's space, after a block barrier) into the [channel][step] layout the 1x1 conv's
-// fragment reads expect, and the second product (K = 16: 4 MFMA steps) runs on it.
+// is exchanged through LDS (the input tile's space, after a block barrier) and the second product (K = 16: 4 MFMA steps) runs on it
+// with the operand roles SWAPPED (D2[co][t], rows = channels): sub-tile n, column l stands for time step 4l + n, so a lane's four
+// accumulators of one channel are 4 consecutive steps and every load / store of the final epilogue (residual, MRF sum, output)
+// covers 4 channel rows x 256 contiguous bytes per wave instruction -- the shape tools/store_shape_bench.hip measures at 1.5x the
+// accumulator layout's 16 rows x 64 B. For that the h2 patch is kept as 4 phase planes [n][channel][l] (time 4l + n).
 #include "conv_common.h"
 #include "film_block.h"
 
@@ -17,14 +20,15 @@ namespace tdvc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
-constexpr int FB_NT = 256, FB_HS = 80;      // time tile; row stride of a wave's h2 patch (16 mod 32: conflict-free fragment reads)
+constexpr int FB_NT = 256, FB_PS = 17, FB_PL = 16 * FB_PS;   // time tile; h2 patch: 4 phase planes of [16 channels][16 + 1] per wave
+constexpr int FB_PATCH = 4 * FB_PL;
 constexpr int FB_XVP = 8, FB_WVP = 4;       // max row-walk passes of the input tile / the conv weight tile
 
 template <bool FILM>
 __global__ __launch_bounds__(256, 5) void film_block_fwd_kernel(const FilmBlockP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int N_REP = 4;
-  float* xs = smem;                               // [16][XS] input tile, later the 4 waves' h2 patches [16][FB_HS]
+  float* xs = smem;                               // [16][XS] input tile, later the 4 waves' h2 patches (4 phase planes each)
   float* ws = smem + p.xs_floats;                 // [16][WS] dilated-conv weights
   float* w2s = ws + p.wnp * p.wrp * p.WS;         // [16][18] 1x1 weights, row = output channel (behind every row the weight walk stages)
 
@@ -108,7 +112,7 @@ __global__ __launch_bounds__(256, 5) void film_block_fwd_kernel(const FilmBlockP
 
   // ---- h = conv + b1 (stored), h2 = LeakyReLU(h * (1 + gamma) + beta) into the wave's LDS patch, [channel][step]
   __syncthreads();                                  // every wave is done reading the input tile
-  float* hp = xs + wave * (16 * FB_HS);
+  float* hp = xs + wave * FB_PATCH;
   {
     const int co = ln;
     const float b1 = p.b1 ? p.b1[co] : 0.f;
@@ -133,14 +137,16 @@ __global__ __launch_bounds__(256, 5) void film_block_fwd_kernel(const FilmBlockP
           for (int q = 0; q < 4; ++q) h2[q] = fmaxf(v[q], v[q] * p.slope);
         }
       }
-      *reinterpret_cast<f32x4*>(hp + co * FB_HS + n * 16 + kq * 4) = h2;
+      // element q of this float4 is time step (n*16 + kq*4 + q) = 4*l + q with l = n*4 + kq: phase plane q, column l
+#pragma unroll
+      for (int q = 0; q < 4; ++q) hp[q * FB_PL + co * FB_PS + n * 4 + kq] = h2[q];
     }
   }
   // wave-private exchange through LDS: DS operations of one wave execute in order; the fences keep the compiler from moving
   // the fragment reads (other lanes' data) above the writes
   __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront"); __builtin_amdgcn_wave_barrier(); __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
 
-  // ---- 1x1 conv: D2[t][co2] += H2[t][k] * W2[k][co2], K = 16 channels = 4 steps
+  // ---- 1x1 conv: D2[co2][t] += W2[co2][k] * H2[k][t], K = 16 channels = 4 steps; sub-tile n, column l = time step 4l + n
   f32x4 acc2[N_REP];
 #pragma unroll
   for (int n = 0; n < N_REP; ++n) acc2[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -149,29 +155,29 @@ __global__ __launch_bounds__(256, 5) void film_block_fwd_kernel(const FilmBlockP
     const float wv2 = w2s[ln * 18 + cs * 4 + kq];
 #pragma unroll
     for (int n = 0; n < N_REP; ++n) {
-      const float xv2 = hp[(cs * 4 + kq) * FB_HS + n * 16 + ln];
-      acc2[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv2, wv2, acc2[n], 0, 0, 0);
+      const float xv2 = hp[n * FB_PL + (cs * 4 + kq) * FB_PS + ln];
+      acc2[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv2, xv2, acc2[n], 0, 0, 0);
     }
   }
 
-  // ---- out = scale * (D2 + b2 + x) + acc
+  // ---- out = scale * (D2 + b2 + x) + acc: lane = (channels 4*kq .. 4*kq+3, time steps t0 .. t0+3 with t0 = 4*ln)
   {
-    const int co = ln;
-    const float b2 = p.b2 ? p.b2[co] : 0.f;
-    const long ro = (long)co * p.T;
+    const int t0 = n0 + wcol0 + 4 * ln;
+    if (t0 < p.T) {
 #pragma unroll
-    for (int n = 0; n < N_REP; ++n) {
-      const int t0 = n0 + wcol0 + n * 16 + kq * 4;
-      if (t0 >= p.T) continue;
-      const long oi = ro + t0;
-      f32x4 v = acc2[n];
+      for (int r = 0; r < 4; ++r) {
+        const int co = 4 * kq + r;
+        const float b2 = p.b2 ? p.b2[co] : 0.f;
+        const long oi = (long)co * p.T + t0;
+        f32x4 v = (f32x4){acc2[0][r], acc2[1][r], acc2[2][r], acc2[3][r]};
 #pragma unroll
-      for (int q = 0; q < 4; ++q) v[q] += b2;
-      const f32x4 r = *reinterpret_cast<const f32x4*>(p.x + (long)b * p.x_bs + oi);
-      v += r;
-      v *= p.scale;
-      if (p.add) { const f32x4 a4 = *reinterpret_cast<const f32x4*>(p.add + (long)b * p.add_bs + oi); v += a4 * 1.f; }
-      *reinterpret_cast<f32x4*>(p.y + (long)b * p.y_bs + oi) = v;
+        for (int q = 0; q < 4; ++q) v[q] += b2;
+        const f32x4 res = *reinterpret_cast<const f32x4*>(p.x + (long)b * p.x_bs + oi);
+        v += res;
+        v *= p.scale;
+        if (p.add) { const f32x4 a4 = *reinterpret_cast<const f32x4*>(p.add + (long)b * p.add_bs + oi); v += a4 * 1.f; }
+        *reinterpret_cast<f32x4*>(p.y + (long)b * p.y_bs + oi) = v;
+      }
     }
   }
 }
@@ -198,7 +204,7 @@ hipError_t launch_film_block_fwd(FilmBlockP p, int B, hipStream_t st) {
   fb_walk_geometry(16, p.K * 16 / 4, &p.wrp, &p.wnp);
   if (p.xnp > FB_XVP || p.wnp > FB_WVP) return hipErrorNotSupported;
   int xs_floats = p.xnp * p.xrp * p.XS;                      // the row walk may stage a few rows past 16
-  if (xs_floats < 4 * 16 * FB_HS) xs_floats = 4 * 16 * FB_HS; // ... and the same space later holds the 4 waves' h2 patches
+  if (xs_floats < 4 * FB_PATCH) xs_floats = 4 * FB_PATCH;    // ... and the same space later holds the 4 waves' h2 patches
   p.xs_floats = xs_floats;
   const size_t lds = (size_t)(xs_floats + p.wnp * p.wrp * p.WS + 16 * 18) * sizeof(float);
   if (p.wnp * p.wrp < 16) return hipErrorNotSupported;
