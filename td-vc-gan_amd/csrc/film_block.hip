@@ -22,6 +22,7 @@ typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 constexpr int FB_NT = 256, FB_PS = 17, FB_PL = 16 * FB_PS;   // time tile; h2 patch: 4 phase planes of [16 channels][16 + 1] per wave
 constexpr int FB_PATCH = 4 * FB_PL;
+constexpr int FB_XSP = 80, FB_XPL = 16 * FB_XSP;   // input tile: 4 phase planes of [16 channels][80] (16 mod 64: the 4 k-rows of a fragment read hit disjoint banks)
 constexpr int FB_XVP = 8, FB_WVP = 4;       // max row-walk passes of the input tile / the conv weight tile
 
 template <bool FILM>
@@ -52,7 +53,23 @@ __global__ __launch_bounds__(256, 5) void film_block_fwd_kernel(const FilmBlockP
     walk_issue<FB_WVP>(wr, rw, ww, p.wnp);
   }
   const float w2v = p.w2[tid];                     // 256 threads = 16 x 16 weights
-  walk_commit_act<FB_XVP>(xr, xw, p.xnp, xs, p.slope, 1.f, false);
+  // input tile as 4 phase planes: staged column i (time q0 + i) lives at xs[(i & 3) * FB_XPL + row * FB_XSP + (i >> 2)], so that the
+  // fragment read of sub-tile n / tap j -- time step 4l + n + j*d of lane l -- is one phase plane at consecutive indices
+  {
+    const int nvec = p.span >> 2;
+    const int rsub = (int)(((float)tid + 0.5f) * (1.0f / (float)nvec));
+    const int vv = tid - rsub * nvec;
+    if (xw.active) {
+#pragma unroll
+      for (int i = 0; i < FB_XVP; ++i) {
+        if (i < walk_opaque(p.xnp) && i * p.xrp + rsub < 16) {
+          float* d = xs + (i * p.xrp + rsub) * FB_XSP + vv;
+#pragma unroll
+          for (int q = 0; q < 4; ++q) { const float v = xr.v[i][q]; d[q * FB_XPL] = fmaxf(v, v * p.slope); }
+        }
+      }
+    }
+  }
   if (q0 < 0 || q0 + p.span > p.T) {               // reflect halo of the sample's first / last tile
     const int nl = q0 < 0 ? -q0 : 0;
     const int rfirst = p.T - q0;
@@ -68,36 +85,41 @@ __global__ __launch_bounds__(256, 5) void film_block_fwd_kernel(const FilmBlockP
       q = q < 0 ? -q : 2 * (p.T - 1) - q;
       float v = (q >= 0 && q < p.T) ? xrow0[(long)r * p.T + q] : 0.f;
       v = v > 0.f ? v : v * p.slope;
-      xs[r * p.XS + i] = v;
+      xs[(i & 3) * FB_XPL + r * FB_XSP + (i >> 2)] = v;
     }
   }
   walk_commit_w<FB_WVP>(wr, ww, p.wnp, ws);
   w2s[(tid >> 4) * 18 + (tid & 15)] = w2v;
   __syncthreads();
 
-  // ---- dilated conv: D[t][co] += X'[t][k] * W1[k][co], one step = 4 channels of one tap
+  // ---- dilated conv: D[co][t] += W1[co][k] * X'[k][t], one step = 4 channels of one tap; sub-tile n, column l = time step 4l + n
   f32x4 acc[N_REP];
 #pragma unroll
   for (int n = 0; n < N_REP; ++n) acc[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
   {
     const float* w_lane = ws + ln * p.WS + kq * p.K;
-    const float* x_lane = xs + kq * p.XS + wcol0 + ln + p.i0;
+    const float* x_lane = xs + kq * FB_XSP + (wcol0 >> 2) + ln;
     const int nsteps = p.K * 4;
-    int sj = 0, scs = 0, woff = 0, xoff = 0;
+    int sj = 0, scs = 0, woff = 0, cso = 0;
+    int xo[N_REP];                                  // per sub-tile: phase plane + index shift of the current tap (wave-uniform)
+#pragma unroll
+    for (int n = 0; n < N_REP; ++n) { const int e = n + p.i0; xo[n] = (e & 3) * FB_XPL + (e >> 2); }
     auto advance = [&]() {
-      if (++scs == 4) { scs = 0; ++sj; woff = sj; xoff = sj * p.d; }
-      else { woff += 4 * p.K; xoff += 4 * p.XS; }
+      if (++scs == 4) {
+        scs = 0; ++sj; woff = sj; cso = 0;
+#pragma unroll
+        for (int n = 0; n < N_REP; ++n) { const int e = n + sj * p.d + p.i0; xo[n] = (e & 3) * FB_XPL + (e >> 2); }
+      } else { woff += 4 * p.K; cso += 4 * FB_XSP; }
     };
     float wv[2], xv[2][N_REP];
     auto load_frag = [&](int buf) {
       wv[buf] = w_lane[woff];
-      const float* xp = x_lane + xoff;
 #pragma unroll
-      for (int n = 0; n < N_REP; ++n) xv[buf][n] = xp[n * 16];
+      for (int n = 0; n < N_REP; ++n) xv[buf][n] = x_lane[xo[n] + cso];
     };
     auto mma = [&](int buf) {
 #pragma unroll
-      for (int n = 0; n < N_REP; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(xv[buf][n], wv[buf], acc[n], 0, 0, 0);
+      for (int n = 0; n < N_REP; ++n) acc[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(wv[buf], xv[buf][n], acc[n], 0, 0, 0);
     };
     load_frag(0);
     int s = 0;
@@ -110,17 +132,18 @@ __global__ __launch_bounds__(256, 5) void film_block_fwd_kernel(const FilmBlockP
     if (s < nsteps) mma(0);
   }
 
-  // ---- h = conv + b1 (stored), h2 = LeakyReLU(h * (1 + gamma) + beta) into the wave's LDS patch, [channel][step]
+  // ---- h = conv + b1 (stored), h2 = LeakyReLU(h * (1 + gamma) + beta) into the wave's LDS patch; lane = (channels 4*kq .. 4*kq+3,
+  // time steps t0 .. t0+3 with t0 = 4*ln): every global access of this phase covers 4 rows x 256 B per wave instruction
   __syncthreads();                                  // every wave is done reading the input tile
   float* hp = xs + wave * FB_PATCH;
   {
-    const int co = ln;
-    const float b1 = p.b1 ? p.b1[co] : 0.f;
-    const long ro = (long)co * p.T;
+    const int t0 = n0 + wcol0 + 4 * ln;
 #pragma unroll
-    for (int n = 0; n < N_REP; ++n) {
-      const int t0 = n0 + wcol0 + n * 16 + kq * 4;
-      f32x4 v = acc[n];
+    for (int r = 0; r < 4; ++r) {
+      const int co = 4 * kq + r;
+      const float b1 = p.b1 ? p.b1[co] : 0.f;
+      const long ro = (long)co * p.T;
+      f32x4 v = (f32x4){acc[0][r], acc[1][r], acc[2][r], acc[3][r]};
 #pragma unroll
       for (int q = 0; q < 4; ++q) v[q] += b1;
       f32x4 h2 = (f32x4){0.f, 0.f, 0.f, 0.f};
@@ -137,9 +160,9 @@ __global__ __launch_bounds__(256, 5) void film_block_fwd_kernel(const FilmBlockP
           for (int q = 0; q < 4; ++q) h2[q] = fmaxf(v[q], v[q] * p.slope);
         }
       }
-      // element q of this float4 is time step (n*16 + kq*4 + q) = 4*l + q with l = n*4 + kq: phase plane q, column l
+      // element n of this float4 is time step 4*ln + n: phase plane n, column ln
 #pragma unroll
-      for (int q = 0; q < 4; ++q) hp[q * FB_PL + co * FB_PS + n * 4 + kq] = h2[q];
+      for (int n = 0; n < 4; ++n) hp[n * FB_PL + co * FB_PS + ln] = h2[n];
     }
   }
   // wave-private exchange through LDS: DS operations of one wave execute in order; the fences keep the compiler from moving
@@ -203,7 +226,8 @@ hipError_t launch_film_block_fwd(FilmBlockP p, int B, hipStream_t st) {
   fb_walk_geometry(16, p.span / 4, &p.xrp, &p.xnp);
   fb_walk_geometry(16, p.K * 16 / 4, &p.wrp, &p.wnp);
   if (p.xnp > FB_XVP || p.wnp > FB_WVP) return hipErrorNotSupported;
-  int xs_floats = p.xnp * p.xrp * p.XS;                      // the row walk may stage a few rows past 16
+  if ((p.span >> 2) > FB_XSP) return hipErrorNotSupported;
+  int xs_floats = 4 * FB_XPL;                                // input tile: 4 phase planes
   if (xs_floats < 4 * FB_PATCH) xs_floats = 4 * FB_PATCH;    // ... and the same space later holds the 4 waves' h2 patches
   p.xs_floats = xs_floats;
   const size_t lds = (size_t)(xs_floats + p.wnp * p.wrp * p.WS + 16 * 18) * sizeof(float);
