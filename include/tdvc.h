@@ -122,6 +122,9 @@ size_t tdvc_conv_wgrad_workspace(const tdvc_conv_desc* d);
  * are per stream. */
 void tdvc_fold_defer(int on);
 int tdvc_fold_flush(void* stream);
+/* Drop the queued folds of `stream` WITHOUT running them: for the failure paths (a backward pass that raised, an abandoned
+ * graph capture), after which the queued descriptors point into workspace regions that later calls overwrite. */
+void tdvc_fold_reset(void* stream);
 
 /* TEST-ONLY process-global switches (see the conventions above).
  * tdvc_set_force_generic: route convs to the scalar (non-MFMA) kernels, to cross-check the two code paths.
@@ -136,6 +139,9 @@ void tdvc_debug_knob(int which, int value); /* tuning knobs for A/B measurements
 void tdvc_debug_lds_cap(int bytes);   /* tuning knob: LDS bytes per block the lean kernel's chunk-size choice may use (0 = built-in) */
 void tdvc_debug_trace(int on);
 size_t tdvc_debug_trace_dump(char* buf, size_t cap);
+/* TEST-ONLY: fill the LDS of every CU with the bit pattern `word` (e.g. 0xFFFFFFFF = a NaN) so that a kernel which reads
+ * LDS it never wrote shows up as NaN in its output instead of passing on whatever finite data the last kernel left. */
+int tdvc_debug_poison_lds(uint32_t word, void* stream);
 
 /* Fused forward of one FiLM residual block (model/generator.py:96-111), narrow long-sequence case (C == 16, T % 4 == 0, T >= 512,
  * reflect padding (K-1)*dilation/2, 16-byte aligned operands; TDVC_EUNSUPPORTED otherwise -> run the two tdvc_conv_fwd calls):

@@ -2,7 +2,7 @@
 (SURVEY §8f-2): reference Generator / Discriminator / LatentClassifier modules driven with the loop body of train.py
 (:259-316 D-step, :300-308 classifier step with torch.optim.Adam, :320-491 G-step incl. :420-422 / :480 the
 gradient-reversed classification term), conv_enc-stage1 with lambda_latcls = 1, B=2, T=8960, 2 iterations. Stores loss
-scalars and parameter checksums (tests/golden/step_latcls.json) and pins oracle/step.py against it.
+scalars and parameter checksums (tests/golden/step_latcls.json), sampled post-update parameters (step_latcls_update.npz) and pins oracle/step.py against it.
 
     PYTHONDONTWRITEBYTECODE=1 python -m oracle.make_golden_latcls
 """
@@ -77,6 +77,16 @@ def main():
     chk = lambda sd: {k: [float(v.double().sum()), float(v.double().abs().sum())] for k, v in sd.items()}
     json.dump(dict(config='conv_enc-stage1 + lambda_latcls=1', B=B, T=T, iters=iters, losses=log, params_G=chk(G.state_dict()),
                    params_D=chk(D.state_dict()), params_C=chk(C.state_dict())), open(f'{OUT}/step_latcls.json', 'w'))
+    # sampled post-update parameter values + per-tensor update norms, as for the other step fixtures (make_golden.py): the
+    # UPDATE is what a test can observe (an lr = 1e-4 step moves sum|p| by ~1e-5 relative)
+    import numpy as np
+    upd = {}
+    for tag_, sd_after, sd_before in (('G', G.state_dict(), sd_g), ('D', D.state_dict(), sd_d), ('C', C.state_dict(), sd_c)):
+        for k, v in sd_after.items():
+            idx = MG.param_sample_idx(k, v.numel())
+            upd[f'{tag_}/{k}'] = v.detach().reshape(-1)[idx].numpy().astype(np.float32)
+            upd[f'{tag_}/{k}/dnorm'] = np.float64((v.detach().double() - sd_before[k].double()).norm())
+    np.savez_compressed(f'{OUT}/step_latcls_update.npz', **upd)
     allpin = json.load(open(f'{OUT}/PINNING.json'))
     allpin['step_latcls'] = pin
     json.dump(allpin, open(f'{OUT}/PINNING.json', 'w'), indent=1)

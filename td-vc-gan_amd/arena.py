@@ -98,7 +98,9 @@ class ParamArena:
                 self.n_live = off
         self.n_total = off
         self.P = torch.zeros(self.n_total, dtype=torch.float32, device=self.device)
-        self.G = torch.zeros(self.n_total, dtype=torch.float32, device=self.device)
+        # gradients exist for the live prefix only: the dead tail (never-read layers, a frozen feature extractor such as
+        # WavLM-Large with ~316 M parameters) has no gradient storage and is never exchanged
+        self.G = torch.zeros(max(self.n_live, 4), dtype=torch.float32, device=self.device)
         self.params = {}
         self.live_keys = [k for k, _ in live]
         with torch.no_grad():
@@ -194,6 +196,10 @@ class ParamArena:
                                                    self.row_k.data_ptr(), self.nrows, st))
 
     def zero_grad(self):
+        # weight-grad folds still queued at this point can only be leftovers of a pass that did not finish (an exception in
+        # backward, an abandoned graph capture): every completed pass flushes in finish_grads. Their slab pointers are stale.
+        if self.device.type == 'cuda' and not torch.cuda.is_current_stream_capturing():
+            L.lib().tdvc_fold_reset(torch.cuda.current_stream(self.device).cuda_stream)
         self.G.zero_()
         self.dW.zero_()
         for p in self.params.values():

@@ -18,6 +18,7 @@ hipError_t launch_slab_reduce(const float*, int, long, long, float*, int, long, 
 hipError_t launch_bias_grad(const Opnd&, int, int, int, float*, hipStream_t);
 hipError_t fold_flush(hipStream_t st);
 void fold_set_defer(int on);
+void fold_reset(hipStream_t st);
 }  // namespace tdvc
 
 namespace tdvc {
@@ -400,6 +401,7 @@ extern "C" int tdvc_film_cond_fwd(const tdvc_film_cond_args* a, void* stream) {
 
 // Deferred weight-gradient folds (include/tdvc.h)
 extern "C" void tdvc_fold_defer(int on) { tdvc::fold_set_defer(on); }
+extern "C" void tdvc_fold_reset(void* stream) { tdvc::fold_reset((hipStream_t)stream); }
 extern "C" int tdvc_fold_flush(void* stream) {
   const hipError_t e = tdvc::fold_flush((hipStream_t)stream);
   if (e != hipSuccess) return tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));

@@ -1081,6 +1081,13 @@ static hipError_t fold_flush_locked(hipStream_t st) {
 }
 hipError_t fold_flush(hipStream_t st) { std::lock_guard<std::mutex> lk(g_fold_mu); return fold_flush_locked(st); }
 void fold_set_defer(int on) { g_fold_defer = on ? 1 : 0; }
+// Drop the queued folds of a stream without running them (a backward pass that raised, an abandoned graph capture): their
+// slab pointers refer to ring regions that later weight-grad calls overwrite.
+void fold_reset(hipStream_t st) {
+  std::lock_guard<std::mutex> lk(g_fold_mu);
+  auto it = fold_pending().find(st);
+  if (it != fold_pending().end()) { it->second.count = 0; it->second.nblocks = 0; }
+}
 
 hipError_t launch_slab_reduce(const float* slab, int nslab, long stride, long n, float* dw, int rowlen, long dst_row_stride,
                               hipStream_t st, long n_w = -1, float* dbias = nullptr) {

@@ -87,7 +87,9 @@ __global__ __launch_bounds__(256) void small_group_fwd_kernel(const SmallGroupP 
 #pragma unroll
       for (int phi = 0; phi < S; ++phi) {
         const bool ok = j * S + phi < p.K;
-        xv4[phi] = xc[phi * p.CS + j];
+        // taps past K read columns of the tile that nothing staged (e >= span): mask the OPERAND too -- a zero weight alone
+        // would turn a stale Inf / NaN bit pattern in LDS into NaN (0 * x)
+        xv4[phi] = ok ? xc[phi * p.CS + j] : 0.f;
         w4[phi] = ok ? wc[j * S + phi] : (f32x4){0.f, 0.f, 0.f, 0.f};
       }
 #pragma unroll

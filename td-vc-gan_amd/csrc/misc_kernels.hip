@@ -50,6 +50,26 @@ void trace_kernel(const void* fn) {
 extern "C" void tdvc_debug_force_tile(int cfg) { tdvc::g_force_tile = cfg; }
 extern "C" void tdvc_debug_lds_cap(int bytes) { tdvc::g_lds_cap = bytes; }
 extern "C" void tdvc_debug_knob(int which, int value) { if (which >= 0 && which < 8) tdvc::g_knob[which] = value; }
+namespace tdvc {
+__global__ __launch_bounds__(256) void poison_lds_kernel(unsigned word, int nwords, unsigned* sink) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];
+  unsigned* u = reinterpret_cast<unsigned*>(smem);
+  for (int i = threadIdx.x; i < nwords; i += 256) u[i] = word;
+  __syncthreads();
+  // keep the stores alive and make the block stay long enough that every CU hosts several of them
+  unsigned acc = 0;
+  for (int i = threadIdx.x; i < nwords; i += 256) acc ^= u[i];
+  if (acc == 0x12345u && sink) sink[0] = acc;
+}
+}  // namespace tdvc
+extern "C" int tdvc_debug_poison_lds(uint32_t word, void* stream) {
+  auto k = tdvc::poison_lds_kernel;
+  TDVC_BIG_LDS_ONCE(k);
+  // 80 KB per block: two blocks per CU cover its 160 KB; 8 rounds of 512 blocks so that every CU is visited repeatedly
+  hipLaunchKernelGGL(k, dim3(4096), dim3(256), 80 * 1024, (hipStream_t)stream, (unsigned)word, 80 * 1024 / 4, (unsigned*)nullptr);
+  TDVC_CHECK_LAUNCH();
+  return TDVC_OK;
+}
 extern "C" void tdvc_debug_trace(int on) {
   std::lock_guard<std::mutex> lk(tdvc::g_trace_mu);
   if (on == 1) tdvc::g_trace_names.clear();

@@ -54,29 +54,41 @@ class ConvSpec:
 # its own region of a ring buffer (the slabs must survive until the flush), the ring flushes before it wraps, and
 # fold_flush() runs before anything reads the gradients (ParamArena.finish_grads / segment hand-over, tests).
 FOLD_DEFER = os.environ.get('TDVC_FOLD_DEFER', '1') == '1'
-RING_BYTES = int(os.environ.get('TDVC_FOLD_RING_MB', '1024')) << 20
+RING_MIN = 64 << 20                                                    # first allocation
+RING_MAX = int(os.environ.get('TDVC_FOLD_RING_MB', '1024')) << 20      # the ring doubles on a wrap until it reaches this
 _ws = {}
 
 
 def fold_flush(device):
-    """Launch the queued folds of `device`'s current stream (no-op when nothing is queued)."""
+    """Launch the queued folds of `device`'s current stream (no-op when nothing is queued). Everything queued before is
+    then ordered ahead of later launches on the stream, so the ring restarts at its beginning: its high-water mark is
+    the slab volume between two flushes (one backward pass), not of the whole run."""
     if FOLD_DEFER:
         L.check(L.lib().tdvc_fold_flush(torch.cuda.current_stream(device).cuda_stream))
+        ent = _ws.get(device)
+        if ent is not None:
+            ent[1] = 0
 
 
 def workspace(device, nbytes):
-    """A region of `nbytes` for the slabs of one weight-grad call -> (buffer, byte offset). Grow-only outside graph
-    capture (the eager warm-up step sizes it)."""
+    """A region of `nbytes` for the slabs of one weight-grad call -> (buffer, byte offset). The ring is sized by use: it
+    starts at 64 MB and doubles (up to TDVC_FOLD_RING_MB) whenever a pass wraps it outside graph capture -- the eager
+    warm-up step sizes it for the captured one; a wrap that still happens costs one extra fold launch, nothing else."""
     ent = _ws.get(device)
     need = max(nbytes, 1 << 20)
-    if ent is None or ent[0].numel() < need:
-        if torch.cuda.is_current_stream_capturing():
+    capturing = torch.cuda.is_current_stream_capturing()
+    grow = ent is None or ent[0].numel() < need
+    if not grow and FOLD_DEFER and ent[1] + nbytes > ent[0].numel() and ent[0].numel() < RING_MAX and not capturing:
+        grow = True                                  # wrapped: a larger ring saves the mid-pass flush from now on
+        need = max(need, 2 * ent[0].numel())
+    if grow:
+        if capturing:
             raise L.TdvcError('wgrad workspace would have to grow during graph capture: run an eager step first')
         if ent is not None:
             fold_flush(device)
             torch.cuda.current_stream(device).synchronize()
         L.lib().tdvc_fold_defer(1 if FOLD_DEFER else 0)
-        size = max(need * 2, RING_BYTES) if FOLD_DEFER else need
+        size = max(need * 2 if ent is None else need, RING_MIN) if FOLD_DEFER else need
         ent = [torch.empty(size, dtype=torch.uint8, device=device), 0]
         _ws[device] = ent
     if not FOLD_DEFER:

@@ -82,5 +82,10 @@ class GradSync:
                 dist.all_reduce(b, op=dist.ReduceOp.SUM, group=self.group)
                 self.calls += 1
 
-    def broadcast_params(self, arena, src=0):
-        dist.broadcast(arena.P, src=src, group=self.group)
+    def broadcast_params(self, arena, src=0, include_frozen=None):
+        """Rank `src`'s parameters to every rank. The dead tail of the arena travels too while it is small (the layers the
+        forward never reads, SURVEY Q7: keeps checkpoints rank-independent); a large one (> 64 MB: a frozen feature extractor
+        such as WavLM-Large, loaded from the same checkpoint on every rank) only on request."""
+        if include_frozen is None:
+            include_frozen = (arena.n_total - arena.n_live) <= (16 << 20)
+        dist.broadcast(arena.P if include_frozen else arena.P[:arena.n_live], src=src, group=self.group)

@@ -64,22 +64,32 @@ def rel_l2(a, b):
     return float((a - b).norm() / (b.norm() + 1e-30))
 
 
-def assert_grads_close(errs, tol, what='', outlier_frac=0.05, outlier_tol=1e-2):
-    """Per-tensor gradient errors `errs` ({name: err} or {name: (err, tol_k)}) must be within `tol`, except for rare outliers.
+GRAD_OUTLIER_LOG = []      # (what, tensors beyond tol, tensors, worst err / tol) of every assert_grads_close call of the session
 
-    Why outliers are allowed: LeakyReLU's derivative is discontinuous at 0, and the network holds tens of millions of
+
+def assert_grads_close(errs, tol, what='', max_outliers=0, outlier_tol=1e-2):
+    """Per-tensor gradient errors `errs` ({name: err} or {name: (err, tol_k)}) must be within `tol`, except for at most
+    `max_outliers` tensors, none of which may be beyond `outlier_tol`. The count actually seen is printed and logged
+    (GRAD_OUTLIER_LOG -> gpurun_out/grad_outliers.json, tests/conftest.py) so that every caller's `max_outliers` is the
+    OBSERVED count plus a small margin, not a blanket fraction.
+
+    Why outliers exist at all: LeakyReLU's derivative is discontinuous at 0, and the network holds tens of millions of
     pre-activations per step. Two correct fp32 implementations that merely round differently (another channel-chunk
     order in an MFMA accumulation, fma contraction) put an element with |x| < 1 ulp of its summands on different sides
     of the kink about once per run; that single mask flip rescales one element of an activation gradient by 5x and moves
     every upstream parameter gradient of a B=2 test by 0.8*|g_i|/||g|| ~ 2-5e-3 (measured: x = 2^-26 vs 0.0 in the
-    ConvTranspose output feeding the T/2 MRF, tools/grad_dump.py). Systematic errors move (almost) all tensors, so the
-    gate is: at most `outlier_frac` of the tensors beyond `tol`, none beyond `outlier_tol`."""
+    ConvTranspose output feeding the T/2 MRF, tools/grad_dump.py). Systematic errors move (almost) all tensors."""
     items = [(k, v if isinstance(v, tuple) else (v, tol)) for k, v in errs.items()]
     bad = sorted(((e / t, k, e) for k, (e, t) in items if e > t), reverse=True)
+    worst = max((e / t for _, (e, t) in items), default=0.0)
+    GRAD_OUTLIER_LOG.append(dict(what=what, beyond_tol=len(bad), tensors=len(items), worst_over_tol=worst, allowed=max_outliers))
+    print(f'[grad gate] {what}: {len(bad)}/{len(items)} tensors beyond tolerance (allowed {max_outliers}), worst err/tol = {worst:.3g}')
     hard = [(k, e) for k, (e, t) in items if e > max(outlier_tol, t)]
     assert not hard, f'{what}: beyond the outlier bound {outlier_tol}: {hard[:8]}'
-    assert len(bad) <= outlier_frac * max(1, len(items)), \
-        f'{what}: {len(bad)}/{len(items)} tensors beyond tolerance (systematic): {[(k, e) for _, k, e in bad[:8]]}'
+    if os.environ.get('TDVC_GRAD_GATE_SURVEY') == '1':      # measuring run: log the counts, gate only on the hard bound
+        return
+    assert len(bad) <= max_outliers, \
+        f'{what}: {len(bad)}/{len(items)} tensors beyond tolerance, {max_outliers} allowed: {[(k, e) for _, k, e in bad[:8]]}'
 
 
 SESSION_KERNELS = set()      # every conv-family kernel instantiation launched inside a `traced()` block of this session

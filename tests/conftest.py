@@ -31,3 +31,15 @@ def rel_l2(a, b):
     import torch
     a, b = a.detach().double().cpu(), b.detach().double().cpu()
     return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def pytest_sessionfinish(session, exitstatus):
+    """Outlier counts of every gradient gate of the session (tests/common.assert_grads_close) -> gpurun_out/grad_outliers.json."""
+    import json
+    common = sys.modules.get('common')
+    log = getattr(common, 'GRAD_OUTLIER_LOG', None) if common else None
+    if log:
+        out = os.path.join(ROOT, 'gpurun_out')
+        os.makedirs(out, exist_ok=True)
+        with open(os.path.join(out, 'grad_outliers.json'), 'w') as f:
+            json.dump(log, f, indent=1)

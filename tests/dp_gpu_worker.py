@@ -57,8 +57,13 @@ def main():
     early = []
     orig = sync.reduce_segment
 
+    handed = []                                # (arena, seg, copy of the segment's G slice as it was handed over)
+
     def spy(arena, seg):                       # was this segment handed over before the end-of-backward flush?
         early.append((arena is D.arena, seg, arena._finish_queued))
+        # stream-ordered snapshot of what goes to the all-reduce: everything queued so far for this segment (its weight-grad
+        # kernels, the deferred folds flushed for it, its weight-norm fold) and nothing later
+        handed.append((arena, seg, arena.G[arena.seg_bounds[seg]:arena.seg_bounds[seg + 1]].clone()))
         return orig(arena, seg)
     sync.reduce_segment = spy
     for it in range(ITERS):
@@ -71,6 +76,16 @@ def main():
         else:
             assert len(in_backward) >= max(1, len(fired) - 2), (it, fired)
         assert len(fired) == G.arena.nseg + D.arena.nseg, (len(fired), G.arena.nseg, D.arena.nseg)
+        if world == 1:
+            # At world 1 the all-reduce is the identity, so a segment handed over BEFORE its last contribution (a weight-grad
+            # kernel, a deferred fold or a weight-norm fold landing later) would still end up right in G and every parameter
+            # check below would pass. Make that visible: the snapshot taken at hand-over must be bit-equal to the segment's
+            # final gradient (G is not touched between the end of a backward pass and the next zero_grad).
+            torch.cuda.synchronize()
+            late = [(a is D.arena, s_) for a, s_, snap in handed
+                    if not torch.equal(snap, a.G[a.seg_bounds[s_]:a.seg_bounds[s_ + 1]])]
+            assert not late, f'iteration {it}: segments changed after their hand-over to the all-reduce: {late}'
+        handed.clear()
     torch.cuda.synchronize()
     try:
         ts.capture(bt, sx, sy)

@@ -14,7 +14,7 @@ class FakeArena:
     def __init__(self, n_live, n_total, fill):
         self.G = torch.full((n_total,), float(fill))
         self.P = torch.arange(n_total, dtype=torch.float32) * (fill + 1)
-        self.n_live = n_live
+        self.n_live, self.n_total = n_live, n_total
 
 
 def main():
@@ -27,8 +27,11 @@ def main():
     sync.all_reduce(a)
     tot = world * (world + 1) / 2
     assert bool((a.G[:1000] == tot).all()) and bool((a.G[1000:] == rank + 1).all()) and sync.scale == 1.0 / world
-    sync.broadcast_params(a)
-    assert bool((a.P == torch.arange(1010, dtype=torch.float32) * 2).all())      # rank 0 holds arange * (1 + 1)
+    sync.broadcast_params(a, include_frozen=False)          # live prefix only: a (large, frozen) dead tail stays as it was
+    ar = torch.arange(1010, dtype=torch.float32)
+    assert bool((a.P[:1000] == ar[:1000] * 2).all()) and bool((a.P[1000:] == ar[1000:] * (rank + 2)).all())
+    sync.broadcast_params(a)                                 # default: a small dead tail travels too
+    assert bool((a.P == ar * 2).all())      # rank 0 holds arange * (1 + 1)
     # segment pipeline (the product path's schedule): completed segments are reduced as the "backward pass" reports them,
     # the learning pass reduces everything at its end; either way every rank ends with the world sum, dead tail untouched
     A = pkg.arena

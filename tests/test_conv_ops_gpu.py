@@ -129,6 +129,22 @@ def test_conv_fwd_bwd(case, generic, dev):
     assert max(errs.values()) < TOL, errs
 
 
+POISON_CASES = ['grp_64_64_k41_s4_g16', 'grp_16_64_k41_s4', 'dil_c16_k11_d5', 'dil_c64_k3_d5', 'cond2_136_32', 'd5_256_256_k5_lrelu',
+                'down_64_128_s8', 'up_128_64_s8', 'fir_dw8_k33_s2', 'k7_256_128_T50']
+
+
+@pytest.mark.parametrize('case', [c for c in CASES if c[0] in POISON_CASES], ids=[c[0] for c in CASES if c[0] in POISON_CASES])
+def test_conv_with_poisoned_lds(case, dev):
+    """Every kernel family with the LDS of all CUs pre-filled with NaN bit patterns (tdvc_debug_poison_lds): a kernel that
+    reads LDS words it never staged -- masked by a zero WEIGHT only -- turns them into NaN (0 * NaN) instead of passing on
+    whatever finite values the previous kernel happened to leave (small_group_fwd_kernel, taps past K)."""
+    _, L, _ = _mods()
+    st = torch.cuda.current_stream(dev).cuda_stream
+    L.check(L.lib().tdvc_debug_poison_lds(0xFFFFFFFF, st))
+    errs = conv_case_errors(case, dev, 0)
+    assert all(e == e for e in errs.values()) and max(errs.values()) < TOL, errs
+
+
 @pytest.mark.parametrize('cfg', [(16, 3, 1, 900, True, True), (32, 7, 3, 400, True, False), (64, 11, 5, 260, False, True),
                                  (128, 3, 1, 100, True, True), (256, 11, 5, 50, False, False)],
                          ids=['c16k3', 'c32k7d3', 'c64k11d5_enc', 'c128k3', 'c256k11d5_enc'])

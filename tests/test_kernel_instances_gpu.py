@@ -112,6 +112,9 @@ def test_launch_shape_film_block(shape, B, dev):
         errs = OPS.film_block_errors(shape, dev, B=B)
     assert max(errs.values()) < TOL, (errs, sorted(tr.names))
     assert any('conv_lean_kernel' in n for n in tr.names), sorted(tr.names)
+    if shape[0] == 16 and shape[3] >= 512:      # the 16-channel long-sequence blocks run the one-launch forward (film_block.hip)
+        want = 'film_block_fwd_kernel<true>' if shape[4] else 'film_block_fwd_kernel<false>'
+        assert want in tr.names, (want, sorted(tr.names))
 
 
 # (name, cin, cout, k, stride, pad, dil, groups, reflect, transposed, T, pre, post), B

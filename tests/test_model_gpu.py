@@ -264,14 +264,11 @@ def test_train_step_with_latent_classifier_vs_golden(dev):
         errs = {k: abs(float(log[k]) - v) / (abs(v) + 1e-12) for k, v in ref.items()}
         tol = {k: TOL for k in errs}
         assert all(errs[k] < tol[k] for k in errs), (it, errs)
-    for name, model, key in (('G', G, 'params_G'), ('D', D, 'params_D'), ('C', C, 'params_C')):
-        bad = {}
-        for k, v in model.state_dict().items():
-            s, a = gold[key][k]
-            got_a = float(v.double().abs().sum())
-            if abs(got_a - a) > TOL * (abs(a) + 1e-12):
-                bad[k] = (got_a, a)
-        assert not bad, (name, dict(list(bad.items())[:5]))
+    # the parameter UPDATE of G, D and the classifier (Adam, no weight decay) against the reference's: sampled elements +
+    # per-tensor update norms (a checksum of p cannot see whether an lr = 1e-4 optimizer ran)
+    upd = np.load(os.path.join(GOLDEN, 'step_latcls_update.npz'))
+    assert_update_matches_fixture(dict(G=G, D=D, C=C), upd, dict(G=filled_sd('G'), D=filled_sd('D'), C=filled_sd('C')), cfg.lr_g,
+                                  'conv_enc-stage1 + lambda_latcls=1')
 
 
 def test_latent_classifier_grads_vs_oracle(dev):
