@@ -194,6 +194,29 @@ typedef struct {
 size_t tdvc_film_cond0_bwd_workspace(int32_t B, int32_t T, int32_t n_cond, int32_t n_var);
 int tdvc_film_cond0_bwd(const tdvc_film_cond0_bwd_args* a, void* stream);
 
+/* Backward of the whole conditioning network behind cond_var.2's output gradient in ONE kernel (film_cond_fused_bwd.hip):
+ * d_cv0 = LeakyReLU-mask * (cond_var.2 input-grad of dgb) is produced and consumed per tile on chip -- dexc, the excitation
+ * window of dw0 and dk3 as in tdvc_film_cond0_bwd -- and never written to HBM. Replaces tdvc_conv_dgrad (cond_var.2) +
+ * tdvc_film_cond0_bwd. The mask comes from the sign bits the forward stored (cv0_sign_bits, [B][n_cond][T/32], T % 32 == 0)
+ * or, when that is NULL, from the stored fp32 cond_var.0 output (cv0). Needs T % 4 == 0, n_var == 8, n_cond <= 144,
+ * C2 % 32 == 0, wt2 = cond_var.2's effective weight pre-transposed to [n_cond][C2][3]; TDVC_EUNSUPPORTED otherwise. */
+typedef struct {
+  int32_t B, T, n_cond, n_var, C2;
+  const float* dgb; int64_t dgb_bs;                      /* [B][C2][T] */
+  const float* wt2;                                      /* [n_cond][C2][3] */
+  const uint32_t* cv0_sign_bits; int64_t cv0_sign_bits_bs;   /* batch stride in words; or NULL */
+  const float* cv0; int64_t cv0_bs;                      /* [B][n_cond][T], read only when cv0_sign_bits is NULL */
+  const float* exc; int64_t exc_bs;                      /* [B][n_var][T] */
+  const float* w0;                                       /* cond_var.0 effective weight [n_cond][n_cond][3] */
+  float* dexc; int64_t dexc_bs;                          /* [B][n_var][T], optional */
+  float* dk3;                                            /* [B][n_cond][3] */
+  float* dw0;                                            /* weight-gradient accumulator of cond_var.0, optional */
+  void* workspace; size_t workspace_bytes;               /* tdvc_film_cond_bwd_workspace() bytes when dw0 is given */
+  float slope;
+} tdvc_film_cond_bwd_args;
+size_t tdvc_film_cond_bwd_workspace(int32_t B, int32_t T, int32_t n_cond, int32_t n_var);
+int tdvc_film_cond_bwd(const tdvc_film_cond_bwd_args* a, void* stream);
+
 /* k3 [B][n_cond][3] = cond_var.0 restricted to the n_const time-constant speaker-embedding channels of its input,
  * evaluated on a length-3 constant signal with the conv's zero 'same' padding (bias b0 included; w0 = effective weight
  * [n_cond][n_cond][3], emb [B][n_const]). bwd: demb [B][n_const] (optional), and the matching window of dw0 / db0 is

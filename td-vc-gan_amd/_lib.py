@@ -53,6 +53,15 @@ class FilmCond0BwdArgs(C.Structure):
                 ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t)]
 
 
+class FilmCondBwdArgs(C.Structure):
+    _fields_ = [('B', C.c_int32), ('T', C.c_int32), ('n_cond', C.c_int32), ('n_var', C.c_int32), ('C2', C.c_int32),
+                ('dgb', C.c_void_p), ('dgb_bs', C.c_int64), ('wt2', C.c_void_p),
+                ('cv0_sign_bits', C.c_void_p), ('cv0_sign_bits_bs', C.c_int64), ('cv0', C.c_void_p), ('cv0_bs', C.c_int64),
+                ('exc', C.c_void_p), ('exc_bs', C.c_int64), ('w0', C.c_void_p),
+                ('dexc', C.c_void_p), ('dexc_bs', C.c_int64), ('dk3', C.c_void_p), ('dw0', C.c_void_p),
+                ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t), ('slope', C.c_float)]
+
+
 class ConvDgradArgs(C.Structure):
     _fields_ = [('dy', C.c_void_p), ('dy_bs', C.c_int64), ('dy_xf', Xform), ('w', C.c_void_p), ('wt', C.c_void_p),
                 ('epilogue', C.c_int32), ('x_in', C.c_void_p), ('x_in_bs', C.c_int64), ('slope', C.c_float),
@@ -86,6 +95,8 @@ SIGNATURES = {
     'tdvc_conv_wgrad_workspace': (C.c_size_t, [C.POINTER(ConvDesc)]),
     'tdvc_film_cond_fwd': (_i, [C.POINTER(FilmCondArgs), _vp]),
     'tdvc_film_cond0_bwd': (_i, [C.POINTER(FilmCond0BwdArgs), _vp]),
+    'tdvc_film_cond_bwd': (_i, [C.POINTER(FilmCondBwdArgs), _vp]),
+    'tdvc_film_cond_bwd_workspace': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),
     'tdvc_film_block_fwd': (_i, [_vp, _vp]),
     'tdvc_film_k3_fwd': (_i, [_vp, _i64, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp]),
     'tdvc_film_k3_bwd': (_i, [_vp, _vp, _i64, _vp, _vp, _vp, _vp, C.c_int32, C.c_int32, C.c_int32, _vp]),

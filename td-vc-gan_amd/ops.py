@@ -296,6 +296,7 @@ class FilmBlockFn(Function):
 FUSED_FILM_BLOCK = os.environ.get('TDVC_FUSED_FILM_BLOCK', '1') == '1'   # one-launch FiLM block forward at 16 channels (A/B switch)
 FUSED_COND_FWD = os.environ.get('TDVC_FUSED_COND_FWD', '0') == '1'     # single-launch conditioning forward (tdvc_film_cond_fwd)
 SIGN_BIT_MASKS = os.environ.get('TDVC_SIGN_BIT_MASKS', '1') == '1'     # cond_var.2 input-grad reads 1-bit LeakyReLU masks (A/B switch)
+FUSED_COND_BWD = os.environ.get('TDVC_FUSED_COND_BWD', '1') == '1'     # cond_var.2 input-grad + cond_var.0 backward in one launch (tdvc_film_cond_bwd)
 
 
 class FilmCondFn(Function):
@@ -337,14 +338,34 @@ class FilmCondFn(Function):
         dgb = dgb.contiguous()
         B, nc, T = cv0.shape
         conv_wgrad_raw(ctx.s2, cv0, _xf(L.XF_LRELU), dgb, _xf())
-        dcv = conv_dgrad_raw(ctx.s2, dgb, _xf(), T, L.DG_MASK_LRELU, x_in=cv0, x_bits=ctx.bits)
-        # everything that consumes d_cv0 in one pass over it: dexc, the excitation window of cond_var.0's weight-grad, dk3
         lib = L.lib()
         sv = ctx.sv.slot
         nv = exc.shape[1]
         want_w = sv.trainable and (sv.arena is None or sv.arena.wgrad_enabled)
         dexc = torch.empty_like(exc) if ctx.needs_input_grad[0] else None
         dk3 = torch.empty((B, nc, 3), dtype=torch.float32, device=dgb.device)
+        C2 = ctx.s2.cout
+        if FUSED_COND_BWD and ctx.s2.slot.wt and nv == 8 and C2 % 32 == 0 and T % 4 == 0 and nc <= 144 and nc % 4 == 0:
+            # one launch: the 136-channel gradient of cond_var.0's output lives in LDS / registers only (film_cond_fused_bwd.hip)
+            nbytes = lib.tdvc_film_cond_bwd_workspace(B, T, nc, nv) if want_w else 0
+            ws, off = workspace(dgb.device, nbytes) if nbytes else (None, 0)
+            bits = ctx.bits
+            a = L.FilmCondBwdArgs(B, T, nc, nv, C2, dgb.data_ptr(), _bs(dgb), ctx.s2.slot.wt,
+                                  bits.data_ptr() if bits is not None else None, _bs(bits) if bits is not None else 0,
+                                  cv0.data_ptr(), _bs(cv0), exc.data_ptr(), _bs(exc), sv.w,
+                                  dexc.data_ptr() if dexc is not None else None, _bs(dexc) if dexc is not None else 0,
+                                  dk3.data_ptr(), sv.dw if want_w else None,
+                                  ws.data_ptr() + off if ws is not None else None, nbytes if ws is not None else 0, SLOPE)
+            rc = lib.tdvc_film_cond_bwd(C.byref(a), _stream(dgb))
+            if rc != L.EUNSUPPORTED:
+                L.check(rc)
+                if want_w and sv.arena is not None:
+                    sv.arena.note_grad(sv)
+                elif want_w:
+                    fold_flush(dgb.device)
+                return dexc, dk3, None, None, None
+        dcv = conv_dgrad_raw(ctx.s2, dgb, _xf(), T, L.DG_MASK_LRELU, x_in=cv0, x_bits=ctx.bits)
+        # everything that consumes d_cv0 in one pass over it: dexc, the excitation window of cond_var.0's weight-grad, dk3
         nbytes = lib.tdvc_film_cond0_bwd_workspace(B, T, nc, nv) if want_w else 0
         ws, off = workspace(dgb.device, nbytes) if nbytes else (None, 0)
         a = L.FilmCond0BwdArgs(B, T, nc, nv, dcv.data_ptr(), _bs(dcv), exc.data_ptr(), _bs(exc), sv.w,

@@ -223,19 +223,24 @@ def film_block_errors(cfg, dev, B=2):
 
 
 @pytest.mark.parametrize('cfg', [(16, 2048, 2), (64, 600, 3), (128, 260, 2), (32, 64, 2)], ids=['C16_T2048', 'C64_T600', 'C128_T260', 'C32_T64'])
+@pytest.mark.parametrize('fused_bwd', [True, False], ids=['bwd1launch', 'bwd2launch'])
 @pytest.mark.parametrize('fused_fwd', [False, True], ids=['fwd2launch', 'fwd1launch'])
-def test_film_conditioning_fused(cfg, fused_fwd, dev):
-    """tdvc_film_cond_fwd / tdvc_film_cond0_bwd (FiLM conditioning path of model/generator.py:86-92,103 in the split
-    formulation) against float64 autograd of the dense reference formulation
-        gb = cond_var.2(LeakyReLU(cond_var.0(cat([emb.repeat(T), exc]))))."""
+def test_film_conditioning_fused(cfg, fused_fwd, fused_bwd, dev):
+    """tdvc_film_cond_fwd / tdvc_film_cond_bwd / tdvc_film_cond0_bwd (FiLM conditioning path of model/generator.py:86-92,103 in
+    the split formulation) against float64 autograd of the dense reference formulation
+        gb = cond_var.2(LeakyReLU(cond_var.0(cat([emb.repeat(T), exc])))).
+    Ragged cases on purpose: T = 600 / 260 / 64 are not multiples of the fused backward's 60-step chunk or of 32 (fp32 mask
+    source), T = 2048 runs the sign-bit mask with a partial last chunk."""
     ops = _mods()[0]
-    old = ops.FUSED_COND_FWD
-    ops.FUSED_COND_FWD = fused_fwd
+    old = ops.FUSED_COND_FWD, ops.FUSED_COND_BWD
+    ops.FUSED_COND_FWD, ops.FUSED_COND_BWD = fused_fwd, fused_bwd
     try:
-        errs = film_cond_errors(cfg, dev)
+        with traced() as tr:
+            errs = film_cond_errors(cfg, dev)
     finally:
-        ops.FUSED_COND_FWD = old
+        ops.FUSED_COND_FWD, ops.FUSED_COND_BWD = old
     assert max(errs.values()) < TOL, errs
+    assert any(n.startswith('film_cond_bwd_kernel') for n in tr.names) == fused_bwd, sorted(tr.names)
 
 
 def film_cond_errors(cfg, dev):

@@ -172,22 +172,30 @@ def test_launch_shape_conv(case, B, dev):
 LAUNCH_COND = [(16, 16000, 16), (32, 8000, 16), (64, 4000, 16), (128, 500, 32)]
 
 
+@pytest.mark.parametrize('fused_bwd', [True, False], ids=['bwd1launch', 'bwd2launch'])
 @pytest.mark.parametrize('fused_fwd', [False, True], ids=['fwd2launch', 'fwd1launch'])
 @pytest.mark.parametrize('cfg', LAUNCH_COND, ids=[f'C{c}_T{t}_B{b}' for c, t, b in LAUNCH_COND])
-def test_launch_shape_fused_conditioning(cfg, fused_fwd, dev):
-    """FiLM conditioning path (ops.FilmCondFn): forward as the two-launch default and as the single fused launch
-    (tdvc_film_cond_fwd, prologue kind LXF_COND), backward = the one-pass tdvc_film_cond0_bwd in both."""
+def test_launch_shape_fused_conditioning(cfg, fused_fwd, fused_bwd, dev):
+    """FiLM conditioning path (ops.FilmCondFn) at the four decoder stages: forward as the two-launch default and as the single
+    fused launch (tdvc_film_cond_fwd, prologue kind LXF_COND); backward as the step's ONE launch behind cond_var.2's output
+    gradient (tdvc_film_cond_bwd: the 136-channel gradient stays on chip; mask from the forward's sign bits, or from the fp32
+    intermediate where T % 32 != 0) and as the two-launch path it replaces (cond_var.2 input-grad + tdvc_film_cond0_bwd)."""
     ops = importlib.import_module('td-vc-gan_amd').ops
-    old = ops.FUSED_COND_FWD
-    ops.FUSED_COND_FWD = fused_fwd
+    old = ops.FUSED_COND_FWD, ops.FUSED_COND_BWD
+    ops.FUSED_COND_FWD, ops.FUSED_COND_BWD = fused_fwd, fused_bwd
     try:
         with traced() as tr:
             errs = OPS.film_cond_errors(cfg, dev)
     finally:
-        ops.FUSED_COND_FWD = old
+        ops.FUSED_COND_FWD, ops.FUSED_COND_BWD = old
     assert max(errs.values()) < TOL, (errs, sorted(tr.names))
     assert any(n.startswith('conv_lean_kernel') and n.endswith(',4,0>') for n in tr.names) == fused_fwd, sorted(tr.names)
-    assert 'film_cond0_bwd_kernel' in tr.names, sorted(tr.names)
+    if fused_bwd:
+        bits = ops.SIGN_BIT_MASKS and not fused_fwd and cfg[1] % 32 == 0 and cfg[1] >= 512
+        assert ('film_cond_bwd_kernel<true>' if bits else 'film_cond_bwd_kernel<false>') in tr.names, sorted(tr.names)
+        assert 'film_cond0_bwd_kernel' not in tr.names, sorted(tr.names)
+    else:
+        assert 'film_cond0_bwd_kernel' in tr.names, sorted(tr.names)
 
 
 # ------------------------------------------------------------------------------------------------ sign-bit masks
