@@ -85,16 +85,54 @@ def time_launches(torch, calls, iters):
     return e0.elapsed_time(e1) / iters
 
 
-def kernel_table(pkg, dev, B, step_ms, iters=40, manifest=None):
-    """Per-kernel roofline table at the step's launch shapes (B samples per GPU -> every trunk conv sees BL = 2B:
-    decoder [target; identity] conditionings, encoder [real; corrupted], discriminator [real; fake] / [fake; identity];
-    discs 1 and 2 see another x2 from the batched sub-scale pass). `n` = launches of that (op, shape) per iteration of
-    config/conv_enc-stage1.yaml: 9 FiLM blocks per decoder stage, one generator pass and three discriminator calls."""
+RIDGE_F_PER_B = MFMA_F32_PEAK_TF * 1e12 / (HBM_PEAK_GBS * 1e9)      # 19.7 FLOP/byte: below it a kernel is priced against HBM
+
+
+def record_launches(pkg, run_step):
+    """One eager iteration with the launch recorder on (td-vc-gan_amd/ops.py: RECORDER): every conv-family entry point of
+    the step reports its (op, geometry, operand transforms, launch shape). Returns {class: launches per iteration}."""
+    import collections
+    import torch
+    pkg.ops.RECORDER = rec = []
+    try:
+        run_step()
+        torch.cuda.synchronize()
+    finally:
+        pkg.ops.RECORDER = None
+    return collections.Counter(rec)
+
+
+def _conv_label(op, key, B, tin, extra):
+    cin, cout, k, stride, pad, dil, groups, reflect, transposed, out_pad, w_cin, w_cin_off = key
+    role = ''
+    if cin == 136 and not transposed:
+        role = 'FiLM cond_var.2 '
+    elif cin == 8 and cout == 136:
+        role = 'FiLM cond_var.0 excitation window '
+    elif cin == 1024 and cout == 1024 and k == 5:
+        role = 'D layer5 '
+    elif groups > 1 and k == 41:
+        role = 'D grouped strided '
+    elif cin == cout and stride == 1 and k > 1 and reflect:
+        role = 'dilated '
+    name = {'fwd': 'fwd', 'dgrad': 'input-grad', 'wgrad': 'weight-grad'}[op]
+    geo = f'k{k}' + (f' s{stride}' if stride > 1 else '') + (f' d{dil}' if dil > 1 else '') + (f' g{groups}' if groups > 1 else '')
+    return f"{role}{'ConvTranspose1d' if transposed else 'Conv1d'} {cin}->{cout} {geo} T={tin} B={B} {name}" + (f' ({extra})' if extra else '')
+
+
+def kernel_table(pkg, dev, classes, step_ms, iters=20, manifest=None, only_ops=None):
+    """Per-kernel roofline table of EVERY conv-family launch class the recorded iteration issued, each rebuilt at its own
+    launch shape on rotating operand sets (> 600 MB per rotation: nothing is served from the 256 MB Infinity Cache) and timed
+    with HIP events on the launch stream. `classes` = record_launches(): {class tuple: launches per iteration}.
+    Algorithmic bytes of a launch = 4 B x every element of every tensor operand it must read or write once (mask / FiLM /
+    residual operands included; sign-bit masks as 1 bit) + the weights; FLOPs = 2 * B * Tout * Cout * Cin/groups * K
+    (ConvTranspose: Tin). A class is priced against the HBM peak when its arithmetic intensity is below the fp32 ridge
+    (157.3 TF / 8 TB/s = 19.7 FLOP/B), else against the fp32 MFMA peak."""
     import torch
     ops, arena, L = pkg.ops, pkg.arena, pkg._lib
     lib = L.lib()
-    BL = 2 * B
     rows = []
+    keep = []
 
     def traced(call):
         lib.tdvc_debug_trace(1)
@@ -104,11 +142,15 @@ def kernel_table(pkg, dev, B, step_ms, iters=40, manifest=None):
         lib.tdvc_debug_trace(0)
         return ' + '.join(names)
 
-    def add(label, n, bound, alg_bytes, flops, calls, rot_bytes):
+    def add(label, n, alg_bytes, flops, calls, rot_bytes, bound=None):
+        if only_ops is not None and label not in only_ops:
+            return None
         name = traced(calls[0])
         ms = time_launches(torch, calls, iters)
         if manifest is not None:      # tools/microbench_kernels.py: lets the PMC summary map dispatches back to this entry
             manifest.append(dict(op=label, kernels=name.split(' + '), calls=1 + len(calls) + 2 + iters))
+        if bound is None:
+            bound = 'hbm' if flops / max(alg_bytes, 1.0) < RIDGE_F_PER_B else 'mfma'
         ach_b, ach_f = alg_bytes / (ms * 1e-3) / 1e9, flops / (ms * 1e-3) / 1e12
         e = dict(kernel=name, op=label, launches_per_step=n, ms_per_launch=ms, share_of_step=n * ms / step_ms, bound=bound,
                  achieved=ach_b if bound == 'hbm' else ach_f, peak=HBM_PEAK_GBS if bound == 'hbm' else MFMA_F32_PEAK_TF,
@@ -116,158 +158,186 @@ def kernel_table(pkg, dev, B, step_ms, iters=40, manifest=None):
                  rotation_bytes=rot_bytes)
         e['frac'] = e['achieved'] / e['peak']
         rows.append(e)
+        return e
 
-    def conv_case(label, n, bound, cin, cout, k, dil, T, reflect, pre, which, Bc, post=0, film=False, bias3=False, bits=False):
-        pad = (k - 1) * dil // 2
-        spec = ops.ConvSpec(cin, cout, k, 1, pad, dil, 1, reflect)
-        w = torch.randn(cout, cin, k, device=dev) / (cin * k) ** 0.5
+    def rand_bits(shape):
+        return torch.randint(-2 ** 31, 2 ** 31 - 1, shape, dtype=torch.int32, device=dev)
+
+    def conv_class(rec, n):
+        op, key, B, tin = rec[:4]
+        cin, cout, k, stride, pad, dil, groups, reflect, transposed, out_pad, w_cin, w_cin_off = key
+        spec = ops.ConvSpec(cin, cout, k, stride, pad, dil, groups, bool(reflect), bool(transposed), out_pad, w_cin, w_cin_off)
+        tout = spec.tout(tin)
+        wshape = (cin, cout // groups, k) if transposed else (cout, (w_cin or cin) // groups, k)
+        w = torch.randn(wshape, device=dev) / (wshape[1] * k) ** 0.5
         b = torch.randn(cout, device=dev) * 0.1
         dw, db = torch.zeros_like(w), torch.zeros_like(b)
-        wt = w.permute(1, 0, 2).contiguous()
-        spec.slot = arena.ConvSlot(w.data_ptr(), b.data_ptr(), dw.data_ptr(), db.data_ptr(), True, None, wt.data_ptr())
-        k3b = torch.randn(Bc, cout, 3, device=dev) * 0.1 if bias3 else None
-        keep.extend([w, b, dw, db, wt, k3b])
-        # operands of the launch exactly as the step passes them (distinct tensors for input / mask source / output)
-        if which == 'fwd':
-            shapes = dict(x=(Bc, cin, T), y=(Bc, cout, T))
-            if film:
-                shapes.update(gb=(Bc, 2 * cin, T), res=(Bc, cout, T))
-            words = cin + cout + ((2 * cin + cout) if film else 0) + (cout / 32.0 if bits else 0)
-        elif which == 'dgrad':
-            shapes = dict(dy=(Bc, cout, T), dx=(Bc, cin, T))
-            if pre and not bits:
-                shapes['x_in'] = (Bc, cin, T)
+        wt = w.permute(1, 0, 2).contiguous() if (not transposed and groups == 1 and stride == 1) else None
+        xs, ys = (B, cin, tin), (B, cout, tout)
+        FILM, MASKS = L.XF_FILM_LRELU, (L.XF_MASK_LRELU, L.XF_MASK_TANH)
+        shapes, bitshape, extra = {}, None, []
+        if op == 'fwd':
+            _, _, _, _, xk, post, has_res, has_add, has_bias, has_b3, has_bits = rec
+            shapes = dict(x=xs, y=ys)
+            if xk == FILM:
+                shapes['aux'] = (B, 2 * cin, tin); extra.append('h*(1+gamma)+beta, LeakyReLU on load')
+            elif xk in MASKS:
+                shapes['aux'] = xs
+            elif xk == L.XF_LRELU:
+                extra.append('LeakyReLU on load')
+            if has_res:
+                shapes['res'] = ys; extra.append('+ residual')
+            if has_add:
+                shapes['add'] = ys; extra.append('+ add')
+            if has_b3:
+                extra.append('3-valued embedding bias')
+            if has_bits:
+                bitshape = (B, cout, tout // 32); extra.append('sign bits out')
             if post:
-                shapes['act'] = (Bc, cout, T)
-            # bits: the LeakyReLU mask comes as 1 bit per element (tdvc_conv_dgrad_args.x_sign_bits), like the step passes it
-            words = cout + cin + ((cin / 32.0 if bits else cin) if pre else 0) + (cout if post else 0)
+                extra.append({1: 'LeakyReLU', 2: 'tanh'}[post] + ' out')
+        elif op == 'dgrad':
+            _, _, _, _, dyk, epi, has_xin, has_bits, has_add, has_wt = rec
+            has_bias = False
+            shapes = dict(dy=ys, dx=xs)
+            if dyk in MASKS:
+                shapes['act'] = ys; extra.append('activation-grad mask on load')
+            if epi == L.DG_MASK_LRELU:
+                if has_bits:
+                    bitshape = (B, cin, tin // 32); extra.append('1-bit LeakyReLU mask')
+                elif has_xin:
+                    shapes['x_in'] = xs; extra.append('LeakyReLU mask')
+            elif epi == L.DG_FILM:
+                shapes.update(x_in=xs, gb=(B, 2 * cin, tin), dgb=(B, 2 * cin, tin)); extra.append('FiLM backward epilogue')
+            if has_add:
+                shapes['add'] = xs; extra.append('+ add')
+            if not has_wt:
+                wt = None
         else:
-            shapes = dict(x=(Bc, cin, T), dy=(Bc, cout, T))
-            if post:
-                shapes['act'] = (Bc, cout, T)
-            words = cin + cout + (cout if post else 0)
+            _, _, _, _, xk, dyk, has_bias = rec
+            shapes = dict(x=xs, dy=ys)
+            if xk == FILM:
+                shapes['aux'] = (B, 2 * cin, tin); extra.append('FiLM + LeakyReLU on load')
+            elif xk in MASKS:
+                shapes['aux'] = xs
+            if dyk in MASKS:
+                shapes['act'] = ys; extra.append('masked dy')
+            extra.append('+ slab fold')
+        spec.slot = arena.ConvSlot(w.data_ptr(), b.data_ptr() if has_bias else 0, dw.data_ptr(), db.data_ptr() if has_bias else 0, True, None,
+                                   wt.data_ptr() if wt is not None else 0)
+        k3b = torch.randn(B, cout, 3, device=dev) * 0.1 if (op == 'fwd' and rec[9]) else None
         bufs = Bufs(torch, dev, shapes)
-        keep.append(bufs)
+        bitbufs = [rand_bits(bitshape) if bitshape else None for _ in bufs.sets]
+        keep[:] = [w, b, dw, db, wt, k3b, bufs, bitbufs, spec]
         calls = []
-        nbw = (cin if which == 'dgrad' else cout)
-        bitbufs = [torch.randint(-2 ** 31, 2 ** 31 - 1, (Bc, nbw, T // 32), dtype=torch.int32, device=dev) for _ in bufs.sets] if bits else [None] * bufs.n
-        keep.append(bitbufs)
-        for s, bw in zip(bufs.sets, bitbufs):
-            dyxf = (lambda s=s: ops._xf(L.XF_MASK_LRELU, aux=s['act'])) if post else (lambda s=s: ops._xf())
-            if which == 'fwd':
-                xf = ops._xf(L.XF_FILM_LRELU, aux=s['gb']) if film else ops._xf(L.XF_LRELU if pre else L.XF_NONE)
-                calls.append(lambda s=s, xf=xf, bw=bw: ops.conv_fwd_raw(spec, s['x'], xf, post=post, res=s.get('res'), out=s['y'], bias3=k3b, sign_bits=bw))
-            elif which == 'dgrad':
-                calls.append(lambda s=s, f=dyxf, bw=bw: ops.conv_dgrad_raw(spec, s['dy'], f(), T, L.DG_MASK_LRELU if pre else L.DG_PLAIN,
-                                                                           x_in=s.get('x_in'), out=s['dx'], x_bits=bw))
+        for sset, bw in zip(bufs.sets, bitbufs):
+            g = sset.get
+            if op == 'fwd':
+                xf = ops._xf(rec[4], aux=g('aux'))
+                calls.append(lambda s=sset, xf=xf, bw=bw: ops.conv_fwd_raw(spec, s['x'], xf, post=rec[5], res=s.get('res'), add=s.get('add'), out=s['y'],
+                                                                           bias3=k3b, sign_bits=bw))
+            elif op == 'dgrad':
+                calls.append(lambda s=sset, bw=bw: ops.conv_dgrad_raw(spec, s['dy'], ops._xf(rec[4], aux=s.get('act')), tin, rec[5], x_in=s.get('x_in'),
+                                                                      gb=s.get('gb'), dgb=s.get('dgb'), add=s.get('add'), out=s['dx'], x_bits=bw))
             else:
-                xf = ops._xf(L.XF_LRELU if pre else L.XF_NONE)
-                calls.append(lambda s=s, xf=xf, f=dyxf: ops.conv_wgrad_raw(spec, s['x'], xf, s['dy'], f()))
-        alg = 4.0 * Bc * T * words + 4.0 * (w.numel() + cout)
-        add(label, n, bound, alg, 2.0 * Bc * T * cin * cout * k, calls, bufs.bytes_per_rotation)
+                calls.append(lambda s=sset: ops.conv_wgrad_raw(spec, s['x'], ops._xf(rec[4], aux=s.get('aux')), s['dy'], ops._xf(rec[5], aux=s.get('act'))))
+        words = sum(int(torch.Size(sh).numel()) for sh in shapes.values()) + (int(torch.Size(bitshape).numel()) if bitshape else 0)
+        alg = 4.0 * words + 4.0 * (w.numel() + (cout if has_bias else 0))
+        flops = 2.0 * B * (tin if transposed else tout) * cout * (cin // groups) * k
+        return add(_conv_label(op, key, B, tin, ', '.join(extra)), n, alg, flops, calls, bufs.bytes_per_rotation)
 
-    def cond_fwd_case(label, n, C2, T, Bc):
-        nc, nv = 136, 8
-        w0 = torch.randn(nc, nc, 3, device=dev) / (nc * 3) ** 0.5
-        w2 = torch.randn(C2, nc, 3, device=dev) / (nc * 3) ** 0.5
-        b2 = torch.randn(C2, device=dev) * 0.1
-        keep.extend([w0, w2, b2])
-        bufs = Bufs(torch, dev, dict(exc=(Bc, nv, T), k3=(Bc, nc, 3), cv0=(Bc, nc, T), gb=(Bc, C2, T)))
-        keep.append(bufs)
-        st = torch.cuda.current_stream(dev).cuda_stream
-        calls = []
-        for s in bufs.sets:
-            a = L.FilmCondArgs(Bc, T, nc, nv, C2, s['exc'].data_ptr(), s['exc'].stride(0), w0.data_ptr(), s['k3'].data_ptr(), w2.data_ptr(),
-                               b2.data_ptr(), s['cv0'].data_ptr(), s['cv0'].stride(0), s['gb'].data_ptr(), s['gb'].stride(0), 0.2)
-            keep.append(a)
-            calls.append(lambda a=a: L.check(lib.tdvc_film_cond_fwd(C.byref(a), st)))
-        alg = 4.0 * Bc * T * (nv + nc + C2) + 4.0 * (w2.numel() + nc * nv * 3)
-        add(label, n, 'mfma', alg, 2.0 * Bc * T * (C2 * nc * 3 + nc * nv * 3), calls, bufs.bytes_per_rotation)
-
-    def cond0_bwd_case(label, n, T, Bc):
-        nc, nv = 136, 8
-        w0 = torch.randn(nc, nc, 3, device=dev) / (nc * 3) ** 0.5
-        dw0 = torch.zeros_like(w0)
-        keep.extend([w0, dw0])
-        bufs = Bufs(torch, dev, dict(dcv=(Bc, nc, T), exc=(Bc, nv, T), dexc=(Bc, nv, T), dk3=(Bc, nc, 3)))
-        keep.append(bufs)
-        nbytes = lib.tdvc_film_cond0_bwd_workspace(Bc, T, nc, nv)
-        ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
-        keep.append(ws)
-        st = torch.cuda.current_stream(dev).cuda_stream
-        calls = []
-        for s in bufs.sets:
-            a = L.FilmCond0BwdArgs(Bc, T, nc, nv, s['dcv'].data_ptr(), s['dcv'].stride(0), s['exc'].data_ptr(), s['exc'].stride(0), w0.data_ptr(),
-                                   s['dexc'].data_ptr(), s['dexc'].stride(0), s['dk3'].data_ptr(), dw0.data_ptr(), ws.data_ptr(),
-                                   ws.numel() * ws.element_size())
-            keep.append(a)
-            calls.append(lambda a=a: (L.check(lib.tdvc_film_cond0_bwd(C.byref(a), st)), L.check(lib.tdvc_fold_flush(st))))
-        add(label, n, 'hbm', 4.0 * Bc * T * (nc + 2 * nv), 2.0 * Bc * T * nc * nv * 3 * 2, calls, bufs.bytes_per_rotation)
-
-    keep = []
-    stages = [(32, 16000), (64, 8000), (128, 4000), (256, 500)]          # (2C, T) of the four decoder stages
-    for C2, T in stages:
-        tag = f'136->{C2} k3 T={T} B={BL}'
-        sb = ops.SIGN_BIT_MASKS and T % 32 == 0 and T >= 512      # the step's formulation (ops.FilmCondFn)
-        conv_case(f'FiLM cond_var.2 input-grad {tag}' + (' (1-bit LeakyReLU mask)' if sb else ''), 9, 'mfma', 136, C2, 3, 1, T, False, 1, 'dgrad', BL, bits=sb)
-        if ops.FUSED_COND_FWD:
-            cond_fwd_case(f'FiLM conditioning fwd (cond_var.0 fused into cond_var.2) {tag}', 9, C2, T, BL)
-        else:       # the step's default: two launches
-            conv_case(f'FiLM cond_var.0 excitation window 8->136 k3 T={T} B={BL} fwd (+ 3-valued embedding bias' + (', sign bits out)' if sb else ')'), 9, 'hbm',
-                      8, 136, 3, 1, T, False, 0, 'fwd', BL, bias3=True, bits=sb)
-            conv_case(f'FiLM cond_var.2 fwd {tag} (LeakyReLU on load)', 9, 'mfma', 136, C2, 3, 1, T, False, 1, 'fwd', BL)
-        conv_case(f'FiLM cond_var.2 weight-grad {tag}', 9, 'mfma', 136, C2, 3, 1, T, False, 1, 'wgrad', BL)
-        cond0_bwd_case(f'FiLM cond_var.0 backward (dexc + dW window + dk3) 136ch T={T} B={BL}', 9, T, BL)
-        keep.clear()
-    # discriminator layer 5 (1024 -> 1024, k5, T' = 63): disc 0 sees 2B, discs 1/2 see 4B (sub-scale pass batched on top)
-    conv_case(f'D layer5 1024->1024 k5 T=63 B={2 * BL} fwd', 4, 'mfma', 1024, 1024, 5, 1, 63, False, 0, 'fwd', 2 * BL, post=1)
-    conv_case(f'D layer5 1024->1024 k5 T=63 B={2 * BL} input-grad', 4, 'mfma', 1024, 1024, 5, 1, 63, False, 0, 'dgrad', 2 * BL, post=1)
-    conv_case(f'D layer5 1024->1024 k5 T=63 B={2 * BL} weight-grad', 2, 'mfma', 1024, 1024, 5, 1, 63, False, 0, 'wgrad', 2 * BL, post=1)
-    keep.clear()
-    # dilated trunk convs (decoder stage 4: C=16, T=16000; one launch per (k, d) and direction) and the FiLM 1x1 posconv
-    ns = {}
-    for k, d in ((3, 1), (7, 3), (11, 5)):
-        tag = f'dilated Conv1d 16->16 k{k} d{d} T=16000 B={BL}'
-        conv_case(f'{tag} fwd (reflect pad, LeakyReLU-on-load, bias)' + (' [stand-alone launch: replaced in the step by the fused FiLM block]' if ops.FUSED_FILM_BLOCK else ''),
-                  0 if ops.FUSED_FILM_BLOCK else 1, 'hbm', 16, 16, k, d, 16000, True, 1, 'fwd', BL)
-        ns[(k, d)] = rows[-1]
-        conv_case(f'{tag} input-grad (mirror fold + LeakyReLU mask)', 1, 'hbm', 16, 16, k, d, 16000, True, 1, 'dgrad', BL)
-        conv_case(f'{tag} weight-grad', 1, 'hbm', 16, 16, k, d, 16000, True, 1, 'wgrad', BL)
-        keep.clear()
-    def film_block_case(label, n, k, d, T, Bc):
+    def film_block_class(rec, n):
         """The fused FiLM-block forward (film_block.hip): dilated Conv1d + FiLM + 1x1 conv + residual in one launch."""
+        _, Bc, T, k, d, has_gb, has_acc = rec
         w1 = torch.randn(16, 16, k, device=dev) / (16 * k) ** 0.5
         w2 = torch.randn(16, 16, 1, device=dev) / 4.0
         b1, b2 = torch.randn(16, device=dev) * 0.1, torch.randn(16, device=dev) * 0.1
-        keep.extend([w1, w2, b1, b2])
-        bufs = Bufs(torch, dev, dict(x=(Bc, 16, T), gb=(Bc, 32, T), h=(Bc, 16, T), y=(Bc, 16, T)))
-        keep.append(bufs)
+        shapes = dict(x=(Bc, 16, T), h=(Bc, 16, T), y=(Bc, 16, T))
+        if has_gb:
+            shapes['gb'] = (Bc, 32, T)
+        if has_acc:
+            shapes['acc'] = (Bc, 16, T)
+        bufs = Bufs(torch, dev, shapes)
         st = torch.cuda.current_stream(dev).cuda_stream
-        calls = []
+        calls, args = [], []
         for s in bufs.sets:
+            gb, acc = s.get('gb'), s.get('acc')
             a = L.FilmBlockArgs(Bc, 16, T, k, d, s['x'].data_ptr(), s['x'].stride(0), w1.data_ptr(), b1.data_ptr(), s['h'].data_ptr(), s['h'].stride(0),
-                                s['gb'].data_ptr(), s['gb'].stride(0), w2.data_ptr(), b2.data_ptr(), None, 0, 1.0, 0.2, s['y'].data_ptr(), s['y'].stride(0))
-            keep.append(a)
+                                gb.data_ptr() if gb is not None else None, gb.stride(0) if gb is not None else 0, w2.data_ptr(), b2.data_ptr(),
+                                acc.data_ptr() if acc is not None else None, acc.stride(0) if acc is not None else 0, 1.0, 0.2, s['y'].data_ptr(), s['y'].stride(0))
+            args.append(a)
             calls.append(lambda a=a: L.check(lib.tdvc_film_block_fwd(C.byref(a), st)))
-        alg = 4.0 * Bc * T * (16 + 32 + 16 + 16) + 4.0 * (w1.numel() + w2.numel() + 32)
-        add(label, n, 'hbm', alg, 2.0 * Bc * T * 16 * 16 * (k + 1), calls, bufs.bytes_per_rotation)
+        keep[:] = [w1, w2, b1, b2, bufs, args]
+        words = sum(int(torch.Size(sh).numel()) for sh in shapes.values())
+        label = (f'FiLM block fwd 16ch k{k} d{d} T={T} B={Bc}: dilated Conv1d (reflect, LeakyReLU-on-load) + ' + ('FiLM + ' if has_gb else '') +
+                 '1x1 conv + residual' + (' + MRF sum' if has_acc else '') + ', one launch')
+        return add(label, n, 4.0 * words + 4.0 * (w1.numel() + w2.numel() + 32), 2.0 * Bc * T * 16 * 16 * (k + 1), calls, bufs.bytes_per_rotation)
 
-    fused = {}
-    if ops.FUSED_FILM_BLOCK:      # the step's formulation of the 16-channel FiLM blocks: one launch per block and (k, d)
-        for k, d in ((3, 1), (7, 3), (11, 5)):
-            film_block_case(f'FiLM block fwd 16ch k{k} d{d} T=16000 B={BL}: dilated Conv1d (reflect, LeakyReLU-on-load) + FiLM + 1x1 conv + residual, one launch',
-                            1, k, d, 16000, BL)
-            fused[(k, d)] = rows[-1]
-            keep.clear()
-    else:
-        conv_case(f'FiLM 1x1 posconv 16->16 T=16000 B={BL} fwd (h*(1+gamma)+beta on load, + residual)', 9, 'hbm', 16, 16, 1, 1, 16000, False, 1, 'fwd', BL,
-                  film=True)
-    conv_case(f'dilated Conv1d 64->64 k7 d3 T=4000 B={BL} fwd', 2, 'mfma', 64, 64, 7, 3, 4000, True, 1, 'fwd', BL)
+    def cond_bwd_class(rec, n):
+        """Fused backward of the conditioning network behind cond_var.2's output gradient (film_cond_fused_bwd.hip)."""
+        _, Bc, T, nc, nv, C2, has_bits, has_dexc, want_w = rec
+        w0 = torch.randn(nc, nc, 3, device=dev) / (nc * 3) ** 0.5
+        wt2 = torch.randn(nc, C2, 3, device=dev) / (nc * 3) ** 0.5
+        dw0 = torch.zeros_like(w0)
+        shapes = dict(dgb=(Bc, C2, T), exc=(Bc, nv, T), dexc=(Bc, nv, T), dk3=(Bc, nc, 3))
+        if not has_bits:
+            shapes['cv0'] = (Bc, nc, T)
+        bufs = Bufs(torch, dev, shapes)
+        bitbufs = [rand_bits((Bc, nc, T // 32)) if has_bits else None for _ in bufs.sets]
+        ws = torch.empty(max(lib.tdvc_film_cond_bwd_workspace(Bc, T, nc, nv), 1), dtype=torch.uint8, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        calls, args = [], []
+        for s, bw in zip(bufs.sets, bitbufs):
+            cv0 = s.get('cv0')
+            a = L.FilmCondBwdArgs(Bc, T, nc, nv, C2, s['dgb'].data_ptr(), s['dgb'].stride(0), wt2.data_ptr(),
+                                  bw.data_ptr() if bw is not None else None, bw.stride(0) if bw is not None else 0,
+                                  cv0.data_ptr() if cv0 is not None else None, cv0.stride(0) if cv0 is not None else 0,
+                                  s['exc'].data_ptr(), s['exc'].stride(0), w0.data_ptr(), s['dexc'].data_ptr() if has_dexc else None, s['dexc'].stride(0),
+                                  s['dk3'].data_ptr(), dw0.data_ptr() if want_w else None, ws.data_ptr(), ws.numel(), 0.2)
+            args.append(a)
+            calls.append(lambda a=a: (L.check(lib.tdvc_film_cond_bwd(C.byref(a), st)), L.check(lib.tdvc_fold_flush(st))))
+        keep[:] = [w0, wt2, dw0, bufs, bitbufs, ws, args]
+        words = Bc * T * (C2 + 2 * nv + (nc / 32.0 if has_bits else nc))
+        label = (f'FiLM conditioning backward {C2}->136->8 T={T} B={Bc}: cond_var.2 input-grad + ' + ('1-bit ' if has_bits else 'fp32 ') +
+                 'LeakyReLU mask + cond_var.0 backward (dexc, dW window, dk3), one launch (+ slab fold)')
+        return add(label, n, 4.0 * words + 4.0 * (wt2.numel() + nc * nv * 3), 2.0 * Bc * T * nc * (C2 * 3 + 2 * nv * 3), calls, bufs.bytes_per_rotation)
+
+    def cond0_bwd_class(rec, n):
+        _, Bc, T, nc, nv, has_dexc, want_w = rec
+        w0 = torch.randn(nc, nc, 3, device=dev) / (nc * 3) ** 0.5
+        dw0 = torch.zeros_like(w0)
+        bufs = Bufs(torch, dev, dict(dcv=(Bc, nc, T), exc=(Bc, nv, T), dexc=(Bc, nv, T), dk3=(Bc, nc, 3)))
+        ws = torch.empty(max(lib.tdvc_film_cond0_bwd_workspace(Bc, T, nc, nv), 1), dtype=torch.uint8, device=dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        calls, args = [], []
+        for s in bufs.sets:
+            a = L.FilmCond0BwdArgs(Bc, T, nc, nv, s['dcv'].data_ptr(), s['dcv'].stride(0), s['exc'].data_ptr(), s['exc'].stride(0), w0.data_ptr(),
+                                   s['dexc'].data_ptr() if has_dexc else None, s['dexc'].stride(0), s['dk3'].data_ptr(), dw0.data_ptr() if want_w else None,
+                                   ws.data_ptr(), ws.numel())
+            args.append(a)
+            calls.append(lambda a=a: (L.check(lib.tdvc_film_cond0_bwd(C.byref(a), st)), L.check(lib.tdvc_fold_flush(st))))
+        keep[:] = [w0, dw0, bufs, ws, args]
+        return add(f'FiLM cond_var.0 backward (dexc + dW window + dk3) 136ch T={T} B={Bc} (+ slab fold)', n, 4.0 * Bc * T * (nc + 2 * nv),
+                   2.0 * Bc * T * nc * nv * 3 * 2, calls, bufs.bytes_per_rotation)
+
+    handlers = dict(fwd=conv_class, dgrad=conv_class, wgrad=conv_class, film_block_fwd=film_block_class, film_cond_bwd=cond_bwd_class,
+                    film_cond0_bwd=cond0_bwd_class)
+    north = None
+    for rec, n in sorted(classes.items(), key=lambda kv: str(kv[0])):
+        e = handlers[rec[0]](rec, n)
+        if e is not None and rec[0] == 'film_block_fwd' and rec[3] == 3 and rec[4] == 1 and rec[5] and (north is None or e['launches_per_step'] >= north['launches_per_step']):
+            north = e
+        keep.clear()
+        torch.cuda.empty_cache()
+    # the kernel the north star names: the stride-1 dilated Conv1d 16 -> 16 k3 (HBM-bound end of the trunk). In the step it runs
+    # inside the fused FiLM-block forward; the stand-alone conv launch (which the step no longer issues for these blocks) stays
+    # next to it as the un-fused per-conv figure of SURVEY §8(d)
+    BL = max((rec[2] for rec in classes if rec[0] == 'fwd'), default=32)
+    alone = conv_class(('fwd', (16, 16, 3, 1, 1, 1, 1, 1, 0, 0, 0, 0), BL, 16000, L.XF_LRELU, 0, False, False, True, False, False), 0)
     keep.clear()
     torch.cuda.empty_cache()
-    # north star: the kernel that runs the 16 -> 16 k3 dilated Conv1d of the step -- the fused FiLM-block forward when it is on
-    # (the stand-alone conv launch, which the step then no longer issues for these blocks, stays in the table next to it)
-    north = dict(fused[(3, 1)], standalone_conv=dict(ns[(3, 1)])) if fused else ns[(3, 1)]
+    if alone is not None:
+        alone['op'] += ' [stand-alone launch: replaced in the step by the fused FiLM block]' if north is not None else ''
+        north = dict(north, standalone_conv=dict(alone)) if north is not None else alone
     rows.sort(key=lambda e: -e['share_of_step'])
     return rows, north
 
@@ -321,14 +391,26 @@ def cpu_baseline(pkg, cfg_train, iters=3, sd_g=None, ssl=False):
                        'generator forward like the reference does, anomaly detection off)')
 
 
+def lib_sha16():
+    """sha256 (first 16 hex digits) of the HIP library this process runs: ties PMC tables to the build they were taken on."""
+    import hashlib
+    try:
+        return hashlib.sha256(open(os.path.join(ROOT, 'td-vc-gan_amd', 'csrc', 'libtdvc_hip.so'), 'rb').read()).hexdigest()[:16]
+    except OSError:
+        return None
+
+
 def pmc_traffic(op):
-    """HBM bytes per launch of table entry `op` from the committed rocprofv3 PMC passes of this round (separate
-    --pmc FETCH_SIZE / --pmc WRITE_SIZE runs over tools/microbench_kernels.py = this very table; FETCH_SIZE doubled per
-    MI355X_MICROARCH.md): the latest profiles/r*_pmc.json, written by tools/pmc_traffic.py. None when the entry is not in it."""
+    """HBM bytes per launch of table entry `op` from the committed rocprofv3 PMC passes (separate --pmc FETCH_SIZE /
+    --pmc WRITE_SIZE runs over tools/microbench_kernels.py = this very table; FETCH_SIZE doubled per MI355X_MICROARCH.md):
+    the latest profiles/r*_pmc.json written by tools/pmc_traffic.py -- but ONLY when that file was taken on the very library
+    build that is running now (its `lib_sha16`); otherwise None: counters of another build say nothing about this one."""
     import glob
     try:
         files = sorted(glob.glob(os.path.join(ROOT, 'profiles', 'r*_pmc.json')))
         tab = json.load(open(files[-1]))
+        if not tab.get('lib_sha16') or tab['lib_sha16'] != lib_sha16():
+            return None
         return tab.get('entries', {}).get(op, {}).get('hbm_bytes_per_launch')
     except (OSError, ValueError, IndexError):
         return None
@@ -381,6 +463,12 @@ def main():
     ix = pkg.synth.contrastive_indices(B, T // 320, cfg.n_neg, 17 + rank).to(dev)
     iy = pkg.synth.contrastive_indices(B, T // 320, cfg.n_neg, 917 + rank).to(dev)
 
+    # which conv-family launches does one iteration of THIS configuration issue? (recorded on an eager warm-up iteration; the
+    # roofline table below rebuilds every recorded (op, launch shape) class)
+    classes = None
+    if rank == 0 and world == 1 and not args.no_kernel_table:
+        classes = record_launches(pkg, lambda: ts.run(bt, ix, iy))
+
     use_graph = (sync is None) and not args.no_graph      # data-parallel steps run eagerly (see TrainStep.capture)
     launch = 'eager'
     step = None
@@ -390,6 +478,7 @@ def main():
             launch = 'hipGraph replay'
         except Exception as e:      # noqa: BLE001 -- fall back to eager launches rather than lose the measurement
             print(f'[bench] rank {rank}: graph capture failed ({type(e).__name__}: {e}); running eagerly', file=sys.stderr, flush=True)
+            pkg._lib.lib().tdvc_fold_reset(torch.cuda.current_stream(dev).cuda_stream)     # folds queued by the abandoned capture
             step = None
     if step is None:
         def step():
@@ -400,24 +489,47 @@ def main():
     torch.cuda.synchronize()
     if rank == 0:
         print(f'[bench] warm-up done ({args.warmup} steps)', file=sys.stderr, flush=True)
+    if dp:
+        ts.comm_events = []          # bracket every pre-optimizer wait for the gradient all-reduce with an event pair
+    marks = [torch.cuda.Event(enable_timing=True) for _ in range(args.steps + 1)]      # per-step timings (median), no host sync
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     t0 = time.perf_counter()
-    for _ in range(args.steps):
+    marks[0].record()
+    for i in range(args.steps):
         log = step()
+        marks[i + 1].record()
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
     torch.cuda.synchronize()
     dt = time.perf_counter() - t0
+    per_step = sorted(marks[i].elapsed_time(marks[i + 1]) for i in range(args.steps))
+    ms_median = per_step[len(per_step) // 2]
+    my_ms = dt / args.steps * 1e3
+    dp_info = None
+    if dp:
+        ev = ts.comm_events or []
+        exposed = sum(a.elapsed_time(b) for a, b in ev) / max(1, args.steps)
+        # proof of the collective's world size: an all-reduce of ones over the process group that carried the gradients
+        ones = torch.ones(1, device=dev)
+        dist.all_reduce(ones)
+        stats = torch.tensor([my_ms, exposed], device=dev, dtype=torch.float64)
+        allst = [torch.zeros_like(stats) for _ in range(world)]
+        dist.all_gather(allst, stats)
+        dp_info = dict(rccl_world=int(round(float(ones))), backend=dist.get_backend(), per_rank_ms=[round(float(t_[0]), 3) for t_ in allst],
+                       exposed_comm_ms=[round(float(t_[1]), 4) for t_ in allst], allreduce_calls_per_step=sync.calls / max(1, args.steps + args.warmup),
+                       grad_segments=dict(G=G.arena.nseg, D=D.arena.nseg), grad_bytes=4 * (G.arena.n_live + D.arena.n_live),
+                       how='exposed_comm_ms = per step, time the compute stream waited for the side-stream all-reduces right before the two optimizer '
+                           'launches (event pair around GradSync.wait); everything else of the exchange ran under the backward pass')
     if world > 1:
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     g_loss = float(log['G_loss'])
     if rank == 0:
-        print(f'[bench] timed region: {dt / args.steps * 1e3:.2f} ms/step', file=sys.stderr, flush=True)
+        print(f'[bench] timed region: {dt / args.steps * 1e3:.2f} ms/step (median of the per-step event timings {ms_median:.2f})', file=sys.stderr, flush=True)
     if not (g_loss == g_loss):
         raise SystemExit('non-finite loss in the timed region')
 
@@ -432,21 +544,39 @@ def main():
                                         'F0 (CREPE) loss term excluded' + (', frozen SSL extractor = synthetic stand-in for WavLM-Large '
                                                                            '(plain PyTorch, inside the timed step)' if ssl else ''),
                                global_batch=world * B, parallelism=f'dp{world}'),
-                   final_G_loss=g_loss, launch=launch)
-        if world == 1 and not args.no_kernel_table and 'stage1' in args.config:      # rank 0 of a multi-rank run goes straight to the JSON line
-            table, north = kernel_table(pkg, dev, B, step_ms)
+                   final_G_loss=g_loss, launch=launch, ms_per_step_median=ms_median,
+                   timing='value / ms_per_step: K steps between two device synchronisations (the contract); ms_per_step_median: median of the K '
+                          'per-step HIP-event timings inside that region')
+        if dp_info is not None:
+            out['data_parallel'] = dp_info
+        if classes is not None:      # rank 0 of a multi-rank run goes straight to the JSON line
+            table, north = kernel_table(pkg, dev, classes, step_ms)
+            try:
+                os.makedirs(os.path.join(ROOT, 'gpurun_out'), exist_ok=True)
+                json.dump(dict(step_ms=step_ms, lib_sha16=lib_sha16(), table=table), open(os.path.join(ROOT, 'gpurun_out', 'kernel_table.json'), 'w'), indent=1)
+            except OSError:
+                pass
             dom = table[0]
             roof = {k: dom[k] for k in ('bound', 'achieved', 'peak', 'unit', 'frac', 'kernel', 'op', 'ms_per_launch', 'launches_per_step',
                                         'share_of_step', 'algorithmic_bytes', 'algorithmic_flops')}
             roof['traffic'] = pmc_traffic(dom['op'])
-            roof['how'] = ('dominant kernel of the step by launches x measured time; HIP events on the launch stream over launches that rotate '
+            if roof['traffic'] is not None and dom['bound'] == 'mfma' and roof['traffic'] / (dom['ms_per_launch'] * 1e-3) > 0.4 * HBM_PEAK_GBS * 1e9:
+                roof['bound_note'] = 'also HBM-limited: measured traffic / time exceeds 0.4 of the HBM peak'
+            roof['how'] = ('dominant kernel of the step by launches x measured time, out of EVERY conv-family launch class one recorded iteration '
+                           'issues; HIP events on the launch stream over launches that rotate '
                            f'through {dom["rotation_bytes"] / 1e6:.0f} MB of operand sets (nothing served from the 256 MB Infinity Cache); '
-                           'traffic = rocprofv3 PMC passes committed under profiles/ (null when absent)')
+                           'traffic = rocprofv3 PMC passes committed under profiles/, only when taken on this very library build (else null)')
             # the kernel the north star names: stride-1 dilated Conv1d, 16 -> 16, k3 (HBM-bound end of the trunk)
             roof['north_star_kernel'] = dict(north, traffic=pmc_traffic(north['op']))
             roof['kernels'] = [{k: e[k] for k in ('kernel', 'op', 'launches_per_step', 'ms_per_launch', 'share_of_step', 'bound', 'achieved',
                                                   'peak', 'unit', 'frac')} for e in table[:12]]
             roof['table_share_of_step'] = sum(e['share_of_step'] for e in table)
+            roof['table_entries'] = len(table)
+            by = {}
+            for e in table:
+                by.setdefault(e['bound'], [0.0, 0.0])
+                by[e['bound']][0] += e['share_of_step']; by[e['bound']][1] += e['share_of_step'] * e['frac']
+            roof['share_weighted_frac'] = {k: dict(share_of_step=v[0], mean_frac_of_peak=v[1] / max(v[0], 1e-12)) for k, v in by.items()}
             out['roofline'] = roof
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(pkg, hp.train, sd_g=sd_g, ssl=ssl)

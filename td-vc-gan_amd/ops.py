@@ -101,6 +101,18 @@ def workspace(device, nbytes):
     return ent[0], off
 
 
+# ------------------------------------------------------------------------------- launch recorder (measurement only)
+# bench.py sets RECORDER = [] around ONE eager iteration: every conv-family entry point then appends a description of its
+# call (layer geometry, operand transforms, epilogue, operand shapes -- no tensors), from which the benchmark rebuilds each
+# (op, launch shape) class on rotating operand sets for the roofline table. None = off (the product path: one branch).
+RECORDER = None
+
+
+def _spec_key(spec):
+    return (spec.cin, spec.cout, spec.k, spec.stride, spec.pad, spec.dil, spec.groups, int(spec.reflect),
+            int(spec.kind == L.CONV_TRANSPOSE), spec.out_pad, spec.w_cin, spec.w_cin_off)
+
+
 def _xf(kind=L.XF_NONE, slope=SLOPE, scale=1.0, aux=None):
     if aux is None:
         return L.Xform(kind, slope, scale, None, 0)
@@ -122,6 +134,9 @@ def conv_fwd_raw(spec: ConvSpec, x, x_xf, post=L.POST_NONE, res=None, add=None, 
     d = spec.desc(B, tin)
     y = out if out is not None else torch.empty((B, spec.cout, d.Tout), dtype=torch.float32, device=x.device)
     _check_layout(x); _check_layout(y)
+    if RECORDER is not None:
+        RECORDER.append(('fwd', _spec_key(spec), B, tin, x_xf.kind, post, res is not None, add is not None,
+                         bool((b_ptr if b_ptr is not None else spec.slot.b)), bias3 is not None, sign_bits is not None))
     a = L.ConvFwdArgs(x.data_ptr(), _bs(x), x_xf, w_ptr if w_ptr is not None else spec.slot.w,
                       (b_ptr if b_ptr is not None else spec.slot.b) or None,
                       res.data_ptr() if res is not None else None, _bs(res) if res is not None else 0,
@@ -139,6 +154,9 @@ def conv_dgrad_raw(spec: ConvSpec, dy, dy_xf, tin, epilogue=L.DG_PLAIN, x_in=Non
     d = spec.desc(B, tin)
     dx = out if out is not None else torch.empty((B, spec.cin, tin), dtype=torch.float32, device=dy.device)
     _check_layout(dy); _check_layout(dx)
+    if RECORDER is not None:
+        RECORDER.append(('dgrad', _spec_key(spec), B, tin, dy_xf.kind, epilogue, x_in is not None, x_bits is not None, add is not None,
+                         bool(spec.slot.wt)))
     a = L.ConvDgradArgs(dy.data_ptr(), _bs(dy), dy_xf, spec.slot.w, spec.slot.wt or None, epilogue,
                         x_in.data_ptr() if x_in is not None else None, _bs(x_in) if x_in is not None else 0, SLOPE,
                         gb.data_ptr() if gb is not None else None, _bs(gb) if gb is not None else 0,
@@ -158,6 +176,8 @@ def conv_wgrad_raw(spec: ConvSpec, x, x_xf, dy, dy_xf):
     B, _, tin = x.shape
     d = spec.desc(B, tin)
     lib = L.lib()
+    if RECORDER is not None:
+        RECORDER.append(('wgrad', _spec_key(spec), B, tin, x_xf.kind, dy_xf.kind, bool(s.db)))
     nbytes = lib.tdvc_conv_wgrad_workspace(C.byref(d))
     ws, off = workspace(x.device, nbytes) if nbytes else (None, 0)
     a = L.ConvWgradArgs(x.data_ptr(), _bs(x), x_xf, dy.data_ptr(), _bs(dy), dy_xf, s.dw, s.db or None,
@@ -264,6 +284,8 @@ class FilmBlockFn(Function):
                 h = out = None
             else:
                 L.check(rc)
+                if RECORDER is not None:
+                    RECORDER.append(('film_block_fwd', B, T, cs.k, cs.dil, gb is not None, accc is not None))
         if out is None:
             h = conv_fwd_raw(conv_spec, x, _xf(L.XF_LRELU))
             xf2 = _xf(L.XF_FILM_LRELU, aux=gb) if gb is not None else _xf(L.XF_LRELU)
@@ -359,6 +381,8 @@ class FilmCondFn(Function):
             rc = lib.tdvc_film_cond_bwd(C.byref(a), _stream(dgb))
             if rc != L.EUNSUPPORTED:
                 L.check(rc)
+                if RECORDER is not None:
+                    RECORDER.append(('film_cond_bwd', B, T, nc, nv, C2, bits is not None, dexc is not None, want_w))
                 if want_w and sv.arena is not None:
                     sv.arena.note_grad(sv)
                 elif want_w:
@@ -373,6 +397,8 @@ class FilmCondFn(Function):
                                dk3.data_ptr(), sv.dw if want_w else None,
                                ws.data_ptr() + off if ws is not None else None, nbytes if ws is not None else 0)
         L.check(lib.tdvc_film_cond0_bwd(C.byref(a), _stream(dgb)))
+        if RECORDER is not None:
+            RECORDER.append(('film_cond0_bwd', B, T, nc, nv, dexc is not None, want_w))
         if want_w and sv.arena is not None:
             sv.arena.note_grad(sv)
         elif want_w:

@@ -78,6 +78,7 @@ class TrainStep:
         self.G, self.D, self.cfg, self.device = G, D, cfg, torch.device(device)
         self.reuse_fake = reuse_fake
         self.grad_sync = grad_sync            # parallel.GradSync or None
+        self.comm_events = None               # set to [] to record (backward done, all-reduce joined) event pairs per optimizer step
         ga, da = G.ensure_arena(self.device), D.ensure_arena(self.device)
         self.opt_g = FlatAdamW(ga, cfg.lr_g, cfg.betas, cfg.eps, cfg.weight_decay)
         self.opt_d = FlatAdamW(da, cfg.lr_d, cfg.betas, cfg.eps, cfg.weight_decay)
@@ -117,9 +118,23 @@ class TrainStep:
 
     def d_step(self, batch, log):
         self._d_fwd_bwd(batch, log)       # data-parallel: segment all-reduces were issued during / at the end of backward
-        if self.grad_sync is not None:
-            self.grad_sync.wait(self.D.arena)
+        self._join_sync(self.D.arena)
         self._d_update()
+
+    def _join_sync(self, arena):
+        """Before an optimizer step of a data-parallel run: the compute stream waits for the arena's gradient all-reduces (side
+        stream). With `comm_events` set, the wait is bracketed by two events on the compute stream: their distance is the time
+        the stream sat idle for communication that the backward pass did not cover (the exposed part of the exchange)."""
+        if self.grad_sync is None:
+            return
+        if self.comm_events is not None:
+            e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+            e0.record()
+            self.grad_sync.wait(arena)
+            e1.record()
+            self.comm_events.append((e0, e1))
+        else:
+            self.grad_sync.wait(arena)
 
     def _d_update(self):
         self.opt_d.step(grad_scale=1.0 if self.grad_sync is None else self.grad_sync.scale)
@@ -151,8 +166,7 @@ class TrainStep:
 
     def g_step(self, batch, log, idx_x=None, idx_y=None):
         self._g_fwd_bwd(batch, log, idx_x, idx_y)
-        if self.grad_sync is not None:
-            self.grad_sync.wait(self.G.arena)
+        self._join_sync(self.G.arena)
         self._g_update()
 
     def _g_update(self):
@@ -285,8 +299,7 @@ class TrainStep:
         c_loss = LS.cross_entropy_loss(logits, batch['label_src'])
         self.opt_c.zero_grad()
         c_loss.backward()
-        if self.grad_sync is not None:
-            self.grad_sync.wait(C.arena)
+        self._join_sync(C.arena)
         self.opt_c.step(grad_scale=1.0 if self.grad_sync is None else self.grad_sync.scale)
         C.arena.materialize()
         log['C_loss'] = c_loss.detach()

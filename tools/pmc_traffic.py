@@ -60,10 +60,14 @@ def main():
         if 'SQ_VALU_MFMA_BUSY_CYCLES' in e and 'GRBM_GUI_ACTIVE' in e and e['GRBM_GUI_ACTIVE'] > 0:
             # busy cycles are summed over the 4 SIMDs of every CU, GRBM_GUI_ACTIVE over the 8 XCDs (guide: DVFS section)
             e['mfma_busy_frac'] = e['SQ_VALU_MFMA_BUSY_CYCLES'] / (256 * 4) / (e['GRBM_GUI_ACTIVE'] / 8)
-    doc = dict(entries=entries, note='rocprofv3 --pmc passes over tools/microbench_kernels.py; see tools/pmc_traffic.py')
+    import bench
+    tag = os.environ.get('TDVC_PROFILE_TAG', 'r03')
+    doc = dict(entries=entries, lib_sha16=bench.lib_sha16(),
+               note='rocprofv3 --pmc passes over tools/microbench_kernels.py; see tools/pmc_traffic.py. lib_sha16 = the libtdvc_hip.so build '
+                    'the counters were taken on: bench.py reports `traffic` only when it runs that very build')
     for d in ('profiles', 'gpurun_out'):      # gpurun_out/ is what travels back from the GPU box; profiles/ is what is committed
         if os.path.isdir(os.path.join(ROOT, d)):
-            json.dump(doc, open(os.path.join(ROOT, d, 'r02_pmc.json'), 'w'), indent=1)
+            json.dump(doc, open(os.path.join(ROOT, d, f'{tag}_pmc.json'), 'w'), indent=1)
     for op, e in entries.items():
         print(op)
         print('    ' + '  '.join(f'{k}={v:.4g}' if isinstance(v, float) else f'{k}={v}' for k, v in e.items()))
