@@ -205,4 +205,6 @@ def normalize_kernel_name(s):
             cut = i
             break
     s = s[:cut].replace(' ', '').replace('tdvc::', '').replace('(anonymousnamespace)::', '')
+    if s.startswith('conv_lean_kernel<') and s.endswith(',false>'):      # the defaulted FOLD = false argument is not part of the instance's name
+        s = s[:-len(',false>')] + '>'
     return s

@@ -21,6 +21,7 @@ struct LeanP {
   unsigned* sbits; const unsigned* mbits;   // sign-bit output of the forward epilogue / sign-bit mask source of EPI_MASK ([B][C][T/32] words)
   int sb_bs, mb_bs;                    // their batch strides in words
   int swz;                             // XCD-aware block order (see conv_lean_kernel)
+  int fold, seg, Bn;                   // FOLD: samples per 64-column tile, LDS columns per sample segment, batch size
   int vec;                             // host-checked: T % 4 == 0, every pointer 16-byte aligned, batch strides % 4 == 0
   float slope, in_scale, out_scale, add_scale, m_slope;
 };

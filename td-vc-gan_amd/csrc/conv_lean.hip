@@ -55,7 +55,11 @@ constexpr int lean_min_blocks(int m_rep, int n_rep, int wm, int xfk) {
   if (m_rep == 1 && n_rep == 4 && wm == 1 && xfk == LXF_ACT) return 5;   // 16 x 256 tile, plain prologue: 5 resident blocks (<= 96 VGPRs) is what the HBM-bound convs run at
   return m_rep * n_rep >= 9 ? 2 : ((m_rep * n_rep >= 8 || (wm == 4 && xfk == LXF_FILM)) ? 3 : LEAN_OCC_SMALL);   // (FiLM prologue on 64 x 64: 12 spills at 4)
 }
-template <int M_REP, int N_REP, int WM, int WN, int XFK, int EPI>
+// FOLD: short sequences (T = 16 / 32: discriminator layer 5 of the two sub-sampled discriminators) put p.fold = 64 / T SAMPLES
+// side by side in one 64-column tile -- segment s of the LDS tile holds sample b0 + s with its own zero-padded halo, sub-tile
+// n of the MFMA loop reads from its sample's segment, the epilogue scatters the sub-tiles back to their samples. Without it
+// three quarters (T = 16) or half (T = 32) of every tile's matrix work is padding.
+template <int M_REP, int N_REP, int WM, int WN, int XFK, int EPI, bool FOLD = false>
 __global__ __launch_bounds__(256, lean_min_blocks(M_REP, N_REP, WM, XFK)) void conv_lean_kernel(const LeanP p) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int MT = 16 * M_REP * WM, NT = 16 * N_REP * WN;
@@ -85,7 +89,7 @@ __global__ __launch_bounds__(256, lean_min_blocks(M_REP, N_REP, WM, XFK)) void c
     const int t = wg / gy;
     bx = t % gx; bz = t / gx;
   }
-  const int n0 = bx * NT, r0 = by * MT, b = bz;
+  const int n0 = FOLD ? 0 : bx * NT, r0 = by * MT, b = FOLD ? bz * p.fold : bz;     // FOLD: b = first sample of the tile
   const int wcol0 = wn * 16 * N_REP, wrow0 = wm * 16 * M_REP;
   PROF_DECL
 
@@ -114,7 +118,15 @@ __global__ __launch_bounds__(256, lean_min_blocks(M_REP, N_REP, WM, XFK)) void c
   // Row-walk staging (conv_common.h): thread = (row of the pass, float4 column); a pass covers xrp (wrp) whole rows,
   // so the per-element cost is one buffer load, one offset add and one LDS store -- no index arithmetic in the loop.
   // Rows past the tensor end fall outside the descriptor's range and load as zero.
-  const RowWalk xw = make_walk(tid, p.span >> 2, p.xrp, p.T, p.XS, q0, p.T);
+  RowWalk xw = make_walk(tid, p.span >> 2, p.xrp, p.T, p.XS, q0, p.T);
+  if (FOLD) {   // float4 column vv of the staged row = column vv % nvs of segment vv / nvs: same LDS offset, another sample's row
+    const int nvec = p.span >> 2, nvs = p.seg >> 2;
+    const int rsub = (int)(((float)tid + 0.5f) * (1.0f / (float)nvec));
+    const int vv = tid - rsub * nvec;
+    const int sg = vv / nvs, q = q0 + 4 * (vv - sg * nvs);
+    xw.voff = (xw.active && q >= 0 && q < p.T && b + sg < p.Bn) ? (sg * p.x_bs + rsub * p.T + q) * 4 : 0x7f000000;
+  }
+  const int fold_bytes = FOLD ? (p.fold - 1) * p.x_bs * 4 : 0;      // the descriptors span the tile's samples
   const RowWalk ww = make_walk(tid, jc >> 2, p.wrp, p.Cw, p.WS, 0, 1 << 30);
   RegTile<XVP> xr;
   RegTile<WVP> wr;
@@ -128,7 +140,7 @@ __global__ __launch_bounds__(256, lean_min_blocks(M_REP, N_REP, WM, XFK)) void c
       }
   }
   auto x_issue = [&](int c0) {
-    const srd_t rs = make_srd(xrow0 + (long)c0 * p.T, (p.Cin - c0) * p.T * 4);
+    const srd_t rs = make_srd(xrow0 + (long)c0 * p.T, (p.Cin - c0) * p.T * 4 + fold_bytes);
     walk_issue<XVP>(xr, rs, xw, p.xnp);
   };
   auto w_issue = [&](int c0) {
@@ -240,7 +252,7 @@ __global__ __launch_bounds__(256, lean_min_blocks(M_REP, N_REP, WM, XFK)) void c
         }
       }
     } else if (interior) {   // FiLM / activation-mask prologues: batches of 4 passes, up to three tensors in flight
-      const int xbytes = (p.Cin - c0) * p.T * 4;
+      const int xbytes = (p.Cin - c0) * p.T * 4 + fold_bytes;
       const srd_t rx = make_srd(xrow0 + (long)c0 * p.T, xbytes);
       const srd_t ra = make_srd(arow0 + (long)c0 * p.T, xbytes);
       const srd_t rb = make_srd(arow0 + (long)(p.Cin + c0) * p.T, XFK == LXF_FILM ? xbytes : 0);
@@ -305,13 +317,19 @@ __global__ __launch_bounds__(256, lean_min_blocks(M_REP, N_REP, WM, XFK)) void c
       else { woff += 4 * p.K; xoff += 4 * p.XS; }
     };
     float wv[2][M_REP], xv[2][N_REP];
+    int noff[N_REP];                                       // LDS column of sub-tile n relative to the wave's first column
+#pragma unroll
+    for (int n = 0; n < N_REP; ++n) {
+      const int col = wcol0 + n * 16;
+      noff[n] = FOLD ? (col / p.T) * p.seg + (col % p.T) - wcol0 : n * 16;
+    }
     auto load_frag = [&](int buf) {
       const float* wp = w_lane + woff;
       const float* xp = x_lane + xoff;
 #pragma unroll
       for (int m = 0; m < M_REP; ++m) wv[buf][m] = wp[m * wrep];
 #pragma unroll
-      for (int n = 0; n < N_REP; ++n) xv[buf][n] = xp[n * 16];
+      for (int n = 0; n < N_REP; ++n) xv[buf][n] = xp[FOLD ? noff[n] : n * 16];
     };
     auto mma = [&](int buf) {
 #pragma unroll
@@ -454,7 +472,7 @@ __global__ __launch_bounds__(256, lean_min_blocks(M_REP, N_REP, WM, XFK)) void c
     return;
   }
   // One float4 of the output: channel co, time steps t0 .. t0+3 (all inside the tensor). Returns the stored values.
-  auto epi_store = [&](f32x4 v, const int co, const int t0, const float bias) -> f32x4 {
+  auto epi_store = [&](f32x4 v, const int co, const int t0, const float bias, const int b) -> f32x4 {     // b: the sample (shadows the block's)
     const long oi = (long)co * p.T + t0;
     if (EPI == EPI_FWD) {
 #pragma unroll
@@ -519,9 +537,10 @@ __global__ __launch_bounds__(256, lean_min_blocks(M_REP, N_REP, WM, XFK)) void c
     unsigned sb_word = 0;
 #pragma unroll
     for (int n = 0; n < N_REP; ++n) {
-      const int t0 = n0 + wcol0 + n * 16 + kq * 4;
+      int t0 = n0 + wcol0 + n * 16 + kq * 4, bb = b;
+      if (FOLD) { const int sg = t0 / p.T; t0 -= sg * p.T; bb = b + sg; if (bb >= p.Bn) continue; }
       if (t0 >= p.T) continue;
-      const f32x4 v = epi_store(acc[m][n], co, t0, bias);
+      const f32x4 v = epi_store(acc[m][n], co, t0, bias, bb);
       if (EPI == EPI_FWD && N_REP >= 2 && p.sbits) {
         // sign bits of the stored values: the 4 lanes (kq = 0..3) of a channel are OR-ed with two wave shuffles, and sub-tiles
         // (n, n+1) make one 32-bit word (the wave's first column is a multiple of 32: 16 * N_REP columns per wave, N_REP even)
@@ -548,16 +567,25 @@ static inline void walk_geometry(int rows, int nvec, int* rp, int* np) {
   *np = *rp ? (rows + *rp - 1) / *rp : 1 << 20;
 }
 
-template <int M_REP, int N_REP, int WM, int WN, int XFK, int EPI>
+template <int M_REP, int N_REP, int WM, int WN, int XFK, int EPI, bool FOLD = false>
 static hipError_t lean_launch3(const LeanP& p, int B, hipStream_t st) {
   constexpr int MT = 16 * M_REP * WM, NT = 16 * N_REP * WN;
-  auto k = conv_lean_kernel<M_REP, N_REP, WM, WN, XFK, EPI>;
+  auto k = conv_lean_kernel<M_REP, N_REP, WM, WN, XFK, EPI, FOLD>;
   TDVC_BIG_LDS_ONCE(k); TDVC_TRACE(k);
-  dim3 grid((p.T + NT - 1) / NT, (p.Cout + MT - 1) / MT, B);
+  dim3 grid(FOLD ? 1 : (p.T + NT - 1) / NT, (p.Cout + MT - 1) / MT, FOLD ? (B + p.fold - 1) / p.fold : B);
   LeanP q = p; q.swz = g_knob[0] && (long)grid.x * grid.y * grid.z >= 16;
   const size_t lds = (size_t)(p.xnp * p.xrp * p.XS + p.wnp * p.wrp * p.WS) * sizeof(float);
   hipLaunchKernelGGL(k, grid, dim3(256), lds, st, q);
   return hipGetLastError();
+}
+
+// folded short-sequence launches (64-column tiles only): the pairs discriminator layer 5 uses
+template <int M_REP, int N_REP, int WM, int WN>
+static hipError_t lean_launch_fold(const LeanP& p, int B, int xfk, int epi, hipStream_t st) {
+  if (xfk == LXF_ACT && epi == EPI_FWD) return lean_launch3<M_REP, N_REP, WM, WN, LXF_ACT, EPI_FWD, true>(p, B, st);
+  if (xfk == LXF_ACT && epi == EPI_PLAIN) return lean_launch3<M_REP, N_REP, WM, WN, LXF_ACT, EPI_PLAIN, true>(p, B, st);
+  if (xfk == LXF_MASK_LRELU && epi == EPI_PLAIN) return lean_launch3<M_REP, N_REP, WM, WN, LXF_MASK_LRELU, EPI_PLAIN, true>(p, B, st);
+  return hipErrorNotSupported;
 }
 
 template <int M_REP, int N_REP, int WM, int WN>
@@ -651,6 +679,18 @@ hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st) {
   const int hi = (p.K - 1) * p.d - p.pad + p.mirror;
   p.lo = lo; p.i0 = first - lo;
   p.span = ((NT + hi - lo) + 3) / 4 * 4;
+  // short sequences: several samples per 64-column tile (kernel comment at FOLD)
+  p.fold = 1; p.seg = 0; p.Bn = B;
+  const bool fold_combo = (xfk == LXF_ACT && (epi == EPI_FWD || epi == EPI_PLAIN)) || (xfk == LXF_MASK_LRELU && epi == EPI_PLAIN);
+  if (g_knob[4] == 0 && g_force_tile < 0 && NT == 64 && R >= 32 && (p.T == 16 || p.T == 32) && B >= 64 / p.T && p.vec && !p.reflect && p.mirror == 0 && fold_combo &&
+      !p.sbits && !p.mbits && (!p.aux || p.aux_bs == p.x_bs) && (long)(64 / p.T) * p.x_bs < (1L << 28)) {
+    p.fold = 64 / p.T;
+    p.seg = ((p.T + hi - lo) + 3) / 4 * 4;
+    p.span = p.fold * p.seg;
+    // a quarter / half as many blocks as unfolded: take the 32-row tile unless the 64-row one still fills a round of 1024
+    const long nb64 = (long)((R + 63) / 64) * ((B + p.fold - 1) / p.fold);
+    if (nb64 >= 1024) { MT = 64; cfg = 4; } else { MT = 32; cfg = 6; }
+  }
   p.XS = ((p.span + 15) / 32) * 32 + 16;           // smallest stride >= span that is 16 (mod 32): the 4 rows of a fragment read hit disjoint banks
   const int xvp = (MT >= 144 || NT <= 64) ? 4 : (MT >= 32 ? 12 : 6), wvp = MT >= 48 ? 10 : (MT >= 32 ? 6 : 4);   // = the kernel's XVP / WVP
   // LDS budget per block = what lets the blocks the register budget allows (launch_bounds of the instance) actually be
@@ -664,11 +704,13 @@ hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st) {
     walk_geometry(MT, p.K * cc / 4, &wrp, &wnp);
     const size_t lds = (size_t)(xnp * xrp * p.XS + wnp * wrp * (p.K * cc + 2)) * 4;
     if (lds > lds_cap || wnp > wvp || (xfk == LXF_ACT && xnp > xvp)) continue;
+    if (p.fold > 1 && p.Cin % cc) continue;          // folded tiles: whole channel chunks only (a partial one would run into the next sample)
     Cc = cc; p.xrp = xrp; p.xnp = xnp; p.wrp = wrp; p.wnp = wnp;
   }
   if (!Cc) return hipErrorNotSupported;                  // weight tile would not fit the register prefetch
   p.Cc = Cc;
   p.WS = p.K * Cc + 2;
+  if (p.fold > 1) return cfg == 4 ? lean_launch_fold<1, 4, 4, 1>(p, B, xfk, epi, st) : lean_launch_fold<1, 2, 2, 2>(p, B, xfk, epi, st);
   switch (cfg) {
     case 0: return lean_launch2<1, 4, 1, 4>(p, B, xfk, epi, st);
     case 1: return lean_launch2<2, 4, 1, 4>(p, B, xfk, epi, st);

@@ -198,6 +198,33 @@ def test_launch_shape_fused_conditioning(cfg, fused_fwd, fused_bwd, dev):
         assert 'film_cond0_bwd_kernel' in tr.names, sorted(tr.names)
 
 
+# ------------------------------------------------------------------------------------------------ folded short sequences
+# conv_lean_kernel<..., FOLD = true>: T = 16 / 32 put 4 / 2 samples into one 64-column tile (discriminator layer 5 of the two
+# sub-sampled discriminators). Ragged batches on purpose (B % fold != 0), the step's own (prologue, epilogue) pairs, and the
+# launch shapes of the step. (name, cin, cout, k, stride, pad, dil, groups, reflect, transposed, T, pre, post), B
+FOLD_CASES = [(('fold_c64_k5_T16_lrelu', 64, 64, 5, 1, 2, 1, 1, False, False, 16, 0, 1), 7),
+              (('fold_c128_k5_T32_lrelu', 128, 128, 5, 1, 2, 1, 1, False, False, 32, 0, 1), 5),
+              (('fold_c64_k3_T16_plain', 64, 48, 3, 1, 1, 1, 1, False, False, 16, 0, 0), 9),
+              (('d5_1024_k5_T16', 1024, 1024, 5, 1, 2, 1, 1, False, False, 16, 0, 1), 64),
+              (('d5_1024_k5_T32', 1024, 1024, 5, 1, 2, 1, 1, False, False, 32, 0, 1), 64)]
+
+
+@pytest.mark.parametrize('case,B', FOLD_CASES, ids=[c[0][0] for c in FOLD_CASES])
+def test_folded_short_sequences(case, B, dev):
+    with traced() as tr:
+        errs = OPS.conv_case_errors(case, dev, 0, B=B)
+    assert max(errs.values()) < TOL, (errs, sorted(tr.names))
+    folded = [n for n in tr.names if n.startswith('conv_lean_kernel') and n.endswith(',true>')]
+    assert len(folded) >= 2, sorted(tr.names)          # forward and input-grad both run folded tiles
+    lib = importlib.import_module('td-vc-gan_amd')._lib.lib()
+    lib.tdvc_debug_knob(4, 1)                          # the same case unfolded: same results up to the accumulation order
+    try:
+        errs1 = OPS.conv_case_errors(case, dev, 0, B=B)
+    finally:
+        lib.tdvc_debug_knob(4, 0)
+    assert max(errs1.values()) < TOL, errs1
+
+
 # ------------------------------------------------------------------------------------------------ sign-bit masks
 # tdvc_conv_fwd_args.sign_bits / tdvc_conv_dgrad_args.x_sign_bits: the forward epilogue packs (y > 0) into one bit per element,
 # the LeakyReLU-mask epilogue of the next layer's input-grad reads those words instead of the fp32 tensor (FiLM conditioning:
