@@ -254,6 +254,19 @@ int tdvc_weight_norm_bwd(const float* params, const float* dw, float* grads, con
  * (a DEVICE int32, so that a captured hipGraph stays valid across replays) or, if NULL, from `step`. */
 int tdvc_adamw(float* p, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
                float eps, float weight_decay, int step, const int32_t* step_dev, float grad_scale, void* stream);
+/* The same with one more factor on the gradient read from DEVICE memory (clip_coef_dev[0], or NULL): the gradient-clipping
+ * coefficient of tdvc_grad_clip_coef, so that clipping costs no pass over the gradients and no host synchronisation. */
+int tdvc_adamw_clipped(float* p, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                       float eps, float weight_decay, int step, const int32_t* step_dev, float grad_scale,
+                       const float* clip_coef_dev, void* stream);
+/* torch.nn.utils.clip_grad_norm_ on a flat gradient buffer (/root/reference/train.py:289-290, 489-490): out[0] = min(1, max_norm /
+ * (grad_scale * ||grad||_2 + 1e-6)), out[1] = grad_scale * ||grad||_2 (the norm of the gradient the optimizer sees: with data
+ * parallelism grad holds the all-reduced SUM and grad_scale = 1 / world). Deterministic two-pass reduction; workspace >= 1024
+ * floats. The coefficient is applied by tdvc_adamw_clipped (the gradient buffer itself is left unscaled). */
+int tdvc_grad_clip_coef(const float* grad, int64_t n, float max_norm, float grad_scale, float* workspace, float* out, void* stream);
+/* util.roll_batches on the last axis (/root/reference/util/__init__.py:91-102, used by util.audio.add_jitter, train.py:335-336):
+ * y[b][c][t] = x[b][c][(t - shift[b]) mod T], shift = int64 [B] on the device. */
+int tdvc_roll_batches(const float* x, const int64_t* shift, float* y, int B, int C, int T, void* stream);
 int tdvc_inc_i32(int32_t* p, int32_t by, void* stream);
 
 /* Element-wise / reductions over [B][C][T] tensors. */

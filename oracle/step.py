@@ -35,6 +35,15 @@ class StepConfig:
     weight_decay: float = 1e-2
     n_neg: int = 100
     fft_sizes: tuple = (2048, 1024, 512)
+    # loop switches off in every shipped YAML (train.py:357-360,381-384 / :409-413 / :335-336 / :289-290,489-490 / :259,320 / :195-197)
+    lambda_wave: float = 0.0
+    lambda_converted: float = 0.0
+    jitter_amp: int = 0
+    grad_max_norm_d: float = None
+    grad_max_norm_g: float = None
+    d_step_interval: int = 1
+    g_step_interval: int = 1
+    freeze_subnets: tuple = ()
 
     @staticmethod
     def from_hparams(train: dict) -> 'StepConfig':
@@ -44,7 +53,13 @@ class StepConfig:
                           lambda_spec=float(g('lambda_spec', 0)), lambda_cont_emb=float(g('lambda_cont_emb', 0)),
                           lambda_corrupted=float(g('lambda_corrupted', 0)), lambda_latcls=float(g('lambda_latcls', 0)),
                           lr_g=float(g('lr_g', 1e-4)),
-                          lr_d=float(g('lr_d', 1e-4)), betas=tuple(g('adam_beta', (0.8, 0.99))))
+                          lr_d=float(g('lr_d', 1e-4)), betas=tuple(g('adam_beta', (0.8, 0.99))),
+                          lambda_wave=float(g('lambda_wave', 0) or 0), lambda_converted=float(g('lambda_converted', 0) or 0),
+                          jitter_amp=int(g('jitter_amp', 0) or 0),
+                          grad_max_norm_d=(float(g('grad_max_norm_D')) if g('grad_max_norm_D') is not None else None),
+                          grad_max_norm_g=(float(g('grad_max_norm_G')) if g('grad_max_norm_G') is not None else None),
+                          d_step_interval=int(g('D_step_interval', 1) or 1), g_step_interval=int(g('G_step_interval', 1) or 1),
+                          freeze_subnets=tuple(g('freeze_subnets') or ()))
 
 
 class AdamW:
@@ -80,9 +95,12 @@ class TrainStep:
         extractor `wave [B, L] -> [B, L', 1024]` features (model/ssl_encoder.py:141-145: 160-sample left pad, no grad);
         None = the conv content encoder."""
         self.ssl = ssl_extractor
-        self.g = {k: v.clone().requires_grad_(True) for k, v in sd_g.items()}
+        # train.py:195-197: a frozen encoder = requires_grad False on G.encoder.parameters() (AdamW then skips them: grad None)
+        frozen = (lambda k: k.startswith('encoder.')) if 'encoder' in cfg.freeze_subnets else (lambda k: False)
+        self.g = {k: v.clone().requires_grad_(not frozen(k)) for k, v in sd_g.items()}
         self.d = {k: v.clone().requires_grad_(True) for k, v in sd_d.items()}
         self.cfg = cfg
+        self.iter_count = 0
         self.opt_g = AdamW(self.g, cfg.lr_g, cfg.betas, cfg.eps, cfg.weight_decay)
         self.opt_d = AdamW(self.d, cfg.lr_d, cfg.betas, cfg.eps, cfg.weight_decay)
         # latent classifier (train.py:153-154, optimizer :192 = torch.optim.Adam(lr_d, adam_beta): no weight decay)
@@ -128,10 +146,16 @@ class TrainStep:
         adv = L.lsgan_to_one(out_fake)
         out = dict(G_loss_adv_fake=adv)
         total = adv
+        # train.py:333-341: the loss target is the real signal rolled by a per-sample random shift when jitter_amp > 0
+        # (util.audio.add_jitter -> util.roll_batches: y[b, :, t] = x[b, :, (t - shift_b) mod T]); the draw is an input here
+        xt = x
+        if c.jitter_amp > 0 and (c.lambda_rec > 0 or c.lambda_idt > 0):
+            xt = torch.stack([torch.roll(x[b_], int(batch['jitter'][b_]), dims=-1) for b_ in range(x.shape[0])])
         feats_real = None
         if (c.lambda_rec > 0 or c.lambda_idt > 0) and c.lambda_feat > 0:
             with torch.no_grad():  # only used detached (Q6)
-                _, feats_real = M.discriminator(self.d, x, batch['label_src'], M.disc_subsamples(x))
+                _, feats_real = M.discriminator(self.d, xt, batch['label_src'], M.disc_subsamples(xt))
+        wave_idt = None
         if not c.no_conv and c.lambda_rec > 0:
             # cycle reconstruction (train.py:344-361): the converted signal, detached, converted back to the source speaker
             rec, rec_subs, _ = self._generator(fake.detach(), batch['c_src'], batch['c_f0_src'])
@@ -141,8 +165,11 @@ class TrainStep:
                 out['G_loss_rec_feat'] = L.feature_matching(feats_rec, feats_real)
                 rec_loss = rec_loss + c.lambda_feat * out['G_loss_rec_feat']
             if c.lambda_spec > 0:
-                out['G_loss_rec_spec'] = L.log_mel_l1(rec, x, c.fft_sizes)
+                out['G_loss_rec_spec'] = L.log_mel_l1(rec, xt, c.fft_sizes)
                 rec_loss = rec_loss + c.lambda_spec * out['G_loss_rec_spec']
+            if c.lambda_wave > 0:       # train.py:357-360
+                out['G_loss_rec_wave'] = (x - rec).abs().mean()
+                rec_loss = rec_loss + c.lambda_wave * out['G_loss_rec_wave']
             out['G_loss_rec'] = rec_loss
             total = total + c.lambda_rec * rec_loss
         if c.lambda_idt > 0:
@@ -156,10 +183,15 @@ class TrainStep:
                 out['G_loss_idt_feat'] = L.feature_matching(feats_idt, feats_real)
                 idt_loss = idt_loss + c.lambda_feat * out['G_loss_idt_feat']
             if c.lambda_spec > 0:
-                out['G_loss_idt_spec'] = L.log_mel_l1(idt, x, c.fft_sizes)
+                out['G_loss_idt_spec'] = L.log_mel_l1(idt, xt, c.fft_sizes)
                 idt_loss = idt_loss + c.lambda_spec * out['G_loss_idt_spec']
+            if c.lambda_wave > 0:       # train.py:381-384: `g_loss_rec += lambda_wave * ...` -> weight lambda_rec * lambda_wave in the total
+                out['G_loss_idt_wave'] = wave_idt = (x - idt).abs().mean()
             out['G_loss_idt'] = idt_loss
             total = total + c.lambda_idt * idt_loss
+        if wave_idt is not None and c.lambda_rec != 0:
+            total = total + (c.lambda_rec * c.lambda_wave) * wave_idt
+        # lambda_converted (train.py:409-413) accumulates its term into itself, never into the loss: nothing to add
         if self.c is not None:      # train.py:420-422, :480 — gradient-reversed into the encoder
             out['G_loss_lat_cls'] = torch.nn.functional.cross_entropy(M.latent_classifier(self.c, emb_real), batch['label_src'])
             total = total + c.lambda_latcls * out['G_loss_lat_cls']
@@ -170,31 +202,41 @@ class TrainStep:
         out['G_loss'] = total
         return out
 
+    def _clip(self, params, max_norm):
+        if max_norm is not None:      # train.py:289-290, 489-490
+            torch.nn.utils.clip_grad_norm_([p for p in params.values() if p.grad is not None], max_norm)
+
     def run(self, batch, idx_x, idx_y):
         """One full iteration; returns {name: float} of every logged scalar."""
-        self.opt_d.zero_grad()
-        dl = self.d_losses(batch)
-        dl['D_loss'].backward()
-        self.opt_d.step()
-        self.opt_d.zero_grad()
-        cl = {}
-        if self.c is not None:      # latent-classifier step (train.py:300-308) on the detached content embedding:
-            with torch.no_grad():   # its gradient into G is dead work (G is not stepped here, grads are zeroed before the G-step)
-                emb = self._encoder(batch['signal_real'])
-            self.opt_c.zero_grad()
-            logits = M.latent_classifier(self.c, emb)
-            cl['C_loss'] = torch.nn.functional.cross_entropy(logits, batch['label_src'])
-            cl['C_loss'].backward()
-            self.opt_c.step()
-            self.opt_c.zero_grad()
-        self.opt_g.zero_grad()
-        for p in list(self.d.values()) + (list(self.c.values()) if self.c is not None else []):
-            p.requires_grad_(False)      # D / C grads from the G-step are dead work (Q5): not computed
-        try:
-            gl = self.g_losses(batch, idx_x, idx_y)
-            gl['G_loss'].backward()
-        finally:
+        c, it = self.cfg, self.iter_count
+        self.iter_count += 1
+        dl, cl, gl = {}, {}, {}
+        if it % c.d_step_interval == 0:      # train.py:259
+            self.opt_d.zero_grad()
+            dl = self.d_losses(batch)
+            dl['D_loss'].backward()
+            self._clip(self.d, c.grad_max_norm_d)
+            self.opt_d.step()
+            self.opt_d.zero_grad()
+            if self.c is not None:      # latent-classifier step (train.py:300-308) on the detached content embedding:
+                with torch.no_grad():   # its gradient into G is dead work (G is not stepped here, grads are zeroed before the G-step)
+                    emb = self._encoder(batch['signal_real'])
+                self.opt_c.zero_grad()
+                logits = M.latent_classifier(self.c, emb)
+                cl['C_loss'] = torch.nn.functional.cross_entropy(logits, batch['label_src'])
+                cl['C_loss'].backward()
+                self.opt_c.step()
+                self.opt_c.zero_grad()
+        if it % c.g_step_interval == 0:      # train.py:320
+            self.opt_g.zero_grad()
             for p in list(self.d.values()) + (list(self.c.values()) if self.c is not None else []):
-                p.requires_grad_(True)
-        self.opt_g.step()
-        return {k: float(v) for k, v in {**dl, **cl, **gl}.items()}
+                p.requires_grad_(False)      # D / C grads from the G-step are dead work (Q5): not computed
+            try:
+                gl = self.g_losses(batch, idx_x, idx_y)
+                gl['G_loss'].backward()
+            finally:
+                for p in list(self.d.values()) + (list(self.c.values()) if self.c is not None else []):
+                    p.requires_grad_(True)
+            self._clip(self.g, c.grad_max_norm_g)
+            self.opt_g.step()
+        return {k: float(v.detach()) for k, v in {**dl, **cl, **gl}.items()}

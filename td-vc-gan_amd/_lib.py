@@ -117,6 +117,9 @@ SIGNATURES = {
     'tdvc_weight_norm_fwd_t': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),
     'tdvc_weight_norm_bwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i, _i, _vp]),
     'tdvc_adamw': (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp, _f, _vp]),
+    'tdvc_adamw_clipped': (_i, [_vp, _vp, _vp, _vp, _i64, _f, _f, _f, _f, _f, _i, _vp, _f, _vp, _vp]),
+    'tdvc_grad_clip_coef': (_i, [_vp, _i64, _f, _f, _vp, _vp, _vp]),
+    'tdvc_roll_batches': (_i, [_vp, _vp, _vp, _i, _i, _i, _vp]),
     'tdvc_inc_i32': (_i, [_vp, C.c_int32, _vp]),
     'tdvc_l2norm_fwd': (_i, [_vp, _vp, _vp, _i, _i, _i, _f, _vp]),
     'tdvc_l2norm_bwd': (_i, [_vp, _vp, _vp, _vp, _i, _i, _i, _vp]),

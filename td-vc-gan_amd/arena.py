@@ -84,14 +84,22 @@ class SegmentTracker:
 class ParamArena:
     def __init__(self, module: torch.nn.Module, device, dead_prefixes=(), transposable=(), seg_bytes=8 << 20):
         """transposable: prefixes of weight-normed stride-1, groups==1 convs whose effective weight is also kept
-        pre-transposed as [Cin][Cout][K] (arena WT) for the input-gradient kernel."""
+        pre-transposed as [Cin][Cout][K] (arena WT) for the input-gradient kernel.
+        Layout of P: [trainable | frozen | dead]. Frozen = parameters with requires_grad == False (the reference freezes a
+        sub-network that way, train.py:195-197): the forward reads them, they get no gradient and no optimizer update. Dead =
+        parameters the forward never reads (`dead_prefixes`)."""
         named = list(module.named_parameters())
-        live = [(k, p) for k, p in named if not any(k.startswith(d) for d in dead_prefixes)]
-        dead = [(k, p) for k, p in named if any(k.startswith(d) for d in dead_prefixes)]
+        is_dead = lambda k: any(k.startswith(d) for d in dead_prefixes)
+        live = [(k, p) for k, p in named if not is_dead(k) and p.requires_grad]
+        frozen = [(k, p) for k, p in named if not is_dead(k) and not p.requires_grad]
+        dead = [(k, p) for k, p in named if is_dead(k)]
+        if not live:
+            raise L.TdvcError('ParamArena: the model has no trainable parameter')
+        self.frozen_keys = set(k for k, _ in frozen)
         self.device = torch.device(device)
         self.offsets = {}
         off = 0
-        for k, p in live + dead:
+        for k, p in live + frozen + dead:
             self.offsets[k] = off
             off += (p.numel() + 3) // 4 * 4          # keep every tensor 16-byte aligned
             if k == live[-1][0]:
@@ -104,7 +112,7 @@ class ParamArena:
         self.params = {}
         self.live_keys = [k for k, _ in live]
         with torch.no_grad():
-            for k, p in live + dead:
+            for k, p in live + frozen + dead:
                 o = self.offsets[k]
                 view = self.P[o:o + p.numel()].view(p.shape)
                 view.copy_(p.data.to(self.device, torch.float32))
@@ -114,12 +122,15 @@ class ParamArena:
         # effective-weight arena for weight-normed tensors
         self.wn = []          # (prefix, v_off, g_off, w_off, rows, cols)
         woff = 0
-        for k, p in live:
+        self.nrows_live = 0            # weight-norm rows of trainable tensors come first: only they have a backward fold
+        for k, p in live + frozen:
             if k.endswith('.weight_v'):
                 pre = k[:-len('.weight_v')]
                 rows, cols = p.shape[0], p.numel() // p.shape[0]
                 self.wn.append((pre, self.offsets[k], self.offsets[pre + '.weight_g'], woff, rows, cols))
                 woff += (p.numel() + 3) // 4 * 4
+                if k not in self.frozen_keys:
+                    self.nrows_live += rows
         self.n_w = max(woff, 4)
         self.W = torch.zeros(self.n_w, dtype=torch.float32, device=self.device)
         self.WT = torch.zeros(self.n_w, dtype=torch.float32, device=self.device)
@@ -174,7 +185,10 @@ class ParamArena:
             o = self.offsets[prefix + '.bias']
             b, db = pb + 4 * o, gb + 4 * o
         wt = self.WT.data_ptr() + 4 * self.w_offsets[prefix] if prefix in self.transposed else 0
-        first = self.offsets[prefix + ('.weight_v' if prefix in self.w_offsets else '.weight')]
+        wkey = prefix + ('.weight_v' if prefix in self.w_offsets else '.weight')
+        first = self.offsets[wkey]
+        if wkey in self.frozen_keys:      # read by the forward, never trained: no gradient slices (they would lie outside G)
+            return ConvSlot(w, b, 0, 0, False, self, wt, -1)
         return ConvSlot(w, b, dw, db, True, self, wt, self.seg_of(first))
 
     def seg_of(self, offset: int) -> int:
@@ -244,8 +258,8 @@ class ParamArena:
         if self._track is not None:
             for seg in self._track.finish():
                 self._segment_ready(seg)
-        elif self.nrows:
-            self._fold_rows(0, self.nrows)
+        elif self.nrows_live:
+            self._fold_rows(0, self.nrows_live)
         if not self._grads_attached:
             for k in self.live_keys:
                 p = self.params[k]
@@ -276,15 +290,27 @@ class FlatAdamW:
         self.m = torch.zeros(arena.n_live, dtype=torch.float32, device=arena.device)
         self.v = torch.zeros(arena.n_live, dtype=torch.float32, device=arena.device)
         self.step_dev = torch.zeros(1, dtype=torch.int32, device=arena.device)
+        self._clip_ws = None           # [1024 partials | clip coefficient, total norm]
 
-    def step(self, grad_scale=1.0):
+    def step(self, grad_scale=1.0, max_norm=None):
+        """max_norm: torch.nn.utils.clip_grad_norm_(parameters, max_norm) before the step (train.py:289-290, 489-490): the
+        total 2-norm of the gradient the optimizer sees (grad_scale included: the all-reduced mean under data parallelism) is
+        computed on the device and the clip coefficient min(1, max_norm / (norm + 1e-6)) enters the update as one more
+        gradient factor -- no extra pass over the gradients, no host synchronisation. `last_grad_norm` holds the norm."""
         a = self.a
         st = torch.cuda.current_stream(a.device).cuda_stream
         lib = L.lib()
         L.check(lib.tdvc_inc_i32(self.step_dev.data_ptr(), 1, st))
-        L.check(lib.tdvc_adamw(a.P.data_ptr(), a.G.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), a.n_live,
-                               self.lr, self.betas[0], self.betas[1], self.eps, self.wd, 0, self.step_dev.data_ptr(),
-                               grad_scale, st))
+        coef = None
+        if max_norm is not None:
+            if self._clip_ws is None:
+                self._clip_ws = torch.zeros(1024 + 2, dtype=torch.float32, device=a.device)
+            coef = self._clip_ws.data_ptr() + 4 * 1024
+            L.check(lib.tdvc_grad_clip_coef(a.G.data_ptr(), a.n_live, float(max_norm), grad_scale, self._clip_ws.data_ptr(), coef, st))
+            self.last_grad_norm = self._clip_ws[1025:1026]
+        L.check(lib.tdvc_adamw_clipped(a.P.data_ptr(), a.G.data_ptr(), self.m.data_ptr(), self.v.data_ptr(), a.n_live,
+                                       self.lr, self.betas[0], self.betas[1], self.eps, self.wd, 0, self.step_dev.data_ptr(),
+                                       grad_scale, coef, st))
 
     def zero_grad(self):
         self.a.zero_grad()

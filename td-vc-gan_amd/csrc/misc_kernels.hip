@@ -165,7 +165,9 @@ __global__ __launch_bounds__(256) void wn_bwd_kernel(const float* __restrict__ p
 // ------------------------------------------------------------------------------ AdamW
 __global__ __launch_bounds__(256) void adamw_kernel(float* __restrict__ p, const float* __restrict__ g, float* __restrict__ m,
                                                     float* __restrict__ v, long n, float lr, float b1, float b2, float eps,
-                                                    float wd, float bc1, float bc2_sqrt, float gscale, const int32_t* step_ptr) {
+                                                    float wd, float bc1, float bc2_sqrt, float gscale, const int32_t* step_ptr,
+                                                    const float* gscale_dev) {
+  if (gscale_dev) gscale *= gscale_dev[0];   // gradient-clipping coefficient computed on the device (tdvc_grad_clip_coef)
   if (step_ptr) {   // device-resident step counter: keeps a captured hipGraph valid across replays
     const float st = (float)step_ptr[0];
     bc1 = 1.f - powf(b1, st); bc2_sqrt = sqrtf(1.f - powf(b2, st));
@@ -330,6 +332,145 @@ __global__ __launch_bounds__(256) void cin_bwd_kernel(const float* x, const floa
     const int tg = Tg == 1 ? 0 : t;
     const float xh = (x[ro + t] - mu) * rs, dh = dy[ro + t] * (1.f + ga[tg]);
     dx[ro + t] = rs * (dh - m1 - xh * m2);
+  }
+}
+
+// Single-pass variants: the whole (b, c) row lives in registers (NV float4 per thread, T <= 1024 * NV, rows 16-byte aligned), so
+// x (and dy) are read from HBM once instead of three (two) times: 8 B per element forward, 12-20 B backward. Same arithmetic
+// as the kernels above (mean first, then the centred sum of squares).
+typedef float cin_f4 __attribute__((ext_vector_type(4)));
+template <int NV>
+__global__ __launch_bounds__(256) void cin_fwd_row_kernel(const float* x, const float* gb, float* y, float* mean, float* rstd,
+                                                          int C, int T, int Tg, float eps) {
+  __shared__ float sh[4];
+  const int c = blockIdx.x, b = blockIdx.y, nv = T >> 2;
+  const cin_f4* xr = reinterpret_cast<const cin_f4*>(x + ((long)b * C + c) * T);
+  cin_f4 v[NV];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int e = threadIdx.x + i * 256;
+    v[i] = e < nv ? xr[e] : (cin_f4){0.f, 0.f, 0.f, 0.f};
+    s += (v[i][0] + v[i][1]) + (v[i][2] + v[i][3]);
+  }
+  const float mu = block_sum(s, sh) / T;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    if (threadIdx.x + i * 256 < nv) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { const float d = v[i][k] - mu; q += d * d; }
+    }
+  }
+  const float rs = rsqrtf(block_sum(q, sh) / T + eps);
+  if (threadIdx.x == 0) { mean[(long)b * C + c] = mu; rstd[(long)b * C + c] = rs; }
+  const float* ga = gb + ((long)b * 2 * C + c) * Tg;
+  const float* be = gb + ((long)b * 2 * C + C + c) * Tg;
+  cin_f4* yr = reinterpret_cast<cin_f4*>(y + ((long)b * C + c) * T);
+  const float g1 = Tg == 1 ? 1.f + ga[0] : 0.f, b1 = Tg == 1 ? be[0] : 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int e = threadIdx.x + i * 256;
+    if (e >= nv) continue;
+    cin_f4 o;
+    if (Tg == 1) {
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = g1 * ((v[i][k] - mu) * rs) + b1;
+    } else {
+      const cin_f4 g4 = reinterpret_cast<const cin_f4*>(ga)[e], b4 = reinterpret_cast<const cin_f4*>(be)[e];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) o[k] = (1.f + g4[k]) * ((v[i][k] - mu) * rs) + b4[k];
+    }
+    yr[e] = o;
+  }
+}
+
+template <int NV>
+__global__ __launch_bounds__(256) void cin_bwd_row_kernel(const float* x, const float* gb, const float* dy, const float* mean,
+                                                          const float* rstd, float* dx, float* dgb, int C, int T, int Tg) {
+  __shared__ float sh[4];
+  const int c = blockIdx.x, b = blockIdx.y, nv = T >> 2;
+  const long ro = ((long)b * C + c) * T;
+  const float mu = mean[(long)b * C + c], rs = rstd[(long)b * C + c];
+  const float* ga = gb + ((long)b * 2 * C + c) * Tg;
+  float* dga = dgb + ((long)b * 2 * C + c) * Tg;
+  float* dbe = dgb + ((long)b * 2 * C + C + c) * Tg;
+  const cin_f4* xr = reinterpret_cast<const cin_f4*>(x + ro);
+  const cin_f4* dr = reinterpret_cast<const cin_f4*>(dy + ro);
+  cin_f4 xh[NV], dh[NV];                           // normalised input, gradient wrt it
+  float s1 = 0.f, s2 = 0.f, sg = 0.f, sb = 0.f;
+  const float g1 = Tg == 1 ? 1.f + ga[0] : 0.f;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int e = threadIdx.x + i * 256;
+    xh[i] = dh[i] = (cin_f4){0.f, 0.f, 0.f, 0.f};
+    if (e >= nv) continue;
+    const cin_f4 xv = xr[e], d = dr[e];
+    cin_f4 g4 = {g1, g1, g1, g1};
+    if (Tg != 1) { g4 = reinterpret_cast<const cin_f4*>(ga)[e]; g4 += 1.f; }
+    cin_f4 og, ob;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      xh[i][k] = (xv[k] - mu) * rs; dh[i][k] = d[k] * g4[k];
+      s1 += dh[i][k]; s2 += dh[i][k] * xh[i][k];
+      og[k] = d[k] * xh[i][k]; ob[k] = d[k];
+      sg += og[k]; sb += ob[k];
+    }
+    if (Tg != 1) { reinterpret_cast<cin_f4*>(dga)[e] = og; reinterpret_cast<cin_f4*>(dbe)[e] = ob; }
+  }
+  const float m1 = block_sum(s1, sh) / T, m2 = block_sum(s2, sh) / T;
+  if (Tg == 1) {
+    const float tg_ = block_sum(sg, sh), tb_ = block_sum(sb, sh);
+    if (threadIdx.x == 0) { dga[0] = tg_; dbe[0] = tb_; }
+  }
+  cin_f4* dxr = reinterpret_cast<cin_f4*>(dx + ro);
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int e = threadIdx.x + i * 256;
+    if (e >= nv) continue;
+    cin_f4 o;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) o[k] = rs * (dh[i][k] - m1 - xh[i][k] * m2);
+    dxr[e] = o;
+  }
+}
+
+// ------------------------------------------------------------------------------ gradient clipping, batch roll
+// torch.nn.utils.clip_grad_norm_ (train.py:289-290, 489-490) on the flat gradient arena: pass 1 leaves one partial sum of
+// squares per block, pass 2 (one block, fixed order: deterministic) turns them into
+//   out[0] = min(1, max_norm / (grad_scale * ||g||_2 + 1e-6))   (the clip coefficient),   out[1] = grad_scale * ||g||_2.
+__global__ __launch_bounds__(256) void sumsq_partial_kernel(const float* g, long n, float* part) {
+  __shared__ float sh[4];
+  float s = 0.f;
+  for (long i = (long)blockIdx.x * 256 + threadIdx.x; i < n; i += (long)gridDim.x * 256) s += g[i] * g[i];
+  s = block_sum(s, sh);
+  if (threadIdx.x == 0) part[blockIdx.x] = s;
+}
+__global__ __launch_bounds__(256) void clip_coef_kernel(const float* part, int nparts, float max_norm, float gscale, float* out) {
+  __shared__ double shd[256];
+  double s = 0.0;
+  for (int i = threadIdx.x; i < nparts; i += 256) s += (double)part[i];
+  shd[threadIdx.x] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    double t = 0.0;
+    for (int i = 0; i < 256; ++i) t += shd[i];
+    const float total = gscale * (float)sqrt(t);
+    const float coef = max_norm / (total + 1e-6f);
+    out[0] = coef < 1.f ? coef : 1.f;
+    out[1] = total;
+  }
+}
+// util.roll_batches (util/__init__.py:91-102) along the last axis: y[b][c][t] = x[b][c][(t - shift[b]) mod T]
+__global__ __launch_bounds__(256) void roll_batches_kernel(const float* x, const int64_t* shift, float* y, int C, int T) {
+  const int b = blockIdx.z, c = blockIdx.y;
+  const long ro = ((long)b * C + c) * T;
+  long sft = shift[b] % T;
+  if (sft < 0) sft += T;
+  for (int t = blockIdx.x * 256 + threadIdx.x; t < T; t += gridDim.x * 256) {
+    long src = t - sft;
+    if (src < 0) src += T;
+    y[ro + t] = x[ro + src];
   }
 }
 
@@ -665,9 +806,33 @@ extern "C" int tdvc_adamw(float* p, const float* grad, float* m, float* v, int64
   if (!p || !grad || !m || !v || n <= 0 || (step < 1 && !step_dev)) return tdvc_fail(TDVC_EINVAL, "adamw: bad arguments");
   const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
   hipLaunchKernelGGL(adamw_kernel, dim3(tdvc_grid(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, (long)n, lr, beta1, beta2, eps,
-                     weight_decay, bc1, bc2s, grad_scale == 0.f ? 1.f : grad_scale, step_dev);
+                     weight_decay, bc1, bc2s, grad_scale == 0.f ? 1.f : grad_scale, step_dev, (const float*)nullptr);
   TDVC_CHECK_LAUNCH();
   return TDVC_OK;
+}
+extern "C" int tdvc_adamw_clipped(float* p, const float* grad, float* m, float* v, int64_t n, float lr, float beta1, float beta2,
+                                  float eps, float weight_decay, int step, const int32_t* step_dev, float grad_scale,
+                                  const float* clip_coef_dev, void* stream) {
+  if (!p || !grad || !m || !v || n <= 0 || (step < 1 && !step_dev)) return tdvc_fail(TDVC_EINVAL, "adamw_clipped: bad arguments");
+  const float bc1 = 1.f - powf(beta1, (float)step), bc2s = sqrtf(1.f - powf(beta2, (float)step));
+  hipLaunchKernelGGL(adamw_kernel, dim3(tdvc_grid(n, 256, 4096)), dim3(256), 0, (hipStream_t)stream, p, grad, m, v, (long)n, lr, beta1, beta2, eps,
+                     weight_decay, bc1, bc2s, grad_scale == 0.f ? 1.f : grad_scale, step_dev, clip_coef_dev);
+  TDVC_CHECK_LAUNCH();
+  return TDVC_OK;
+}
+extern "C" int tdvc_grad_clip_coef(const float* grad, int64_t n, float max_norm, float grad_scale, float* workspace, float* out, void* stream) {
+  if (!grad || !workspace || !out || n <= 0 || !(max_norm > 0.f)) return tdvc_fail(TDVC_EINVAL, "grad_clip_coef: bad arguments");
+  const int nparts = tdvc_grid(n, 256, 1024);
+  hipLaunchKernelGGL(sumsq_partial_kernel, dim3(nparts), dim3(256), 0, (hipStream_t)stream, grad, (long)n, workspace);
+  TDVC_CHECK_LAUNCH();
+  hipLaunchKernelGGL(clip_coef_kernel, dim3(1), dim3(256), 0, (hipStream_t)stream, workspace, nparts, max_norm, grad_scale == 0.f ? 1.f : grad_scale, out);
+  TDVC_CHECK_LAUNCH();
+  return TDVC_OK;
+}
+extern "C" int tdvc_roll_batches(const float* x, const int64_t* shift, float* y, int B, int C, int T, void* stream) {
+  if (!x || !shift || !y || B <= 0 || C <= 0 || T <= 0) return tdvc_fail(TDVC_EINVAL, "roll_batches: bad arguments");
+  hipLaunchKernelGGL(roll_batches_kernel, dim3(tdvc_grid(T, 256, 64), C, B), dim3(256), 0, (hipStream_t)stream, x, shift, y, C, T);
+  TDVC_CHECK_LAUNCH(); return TDVC_OK;
 }
 
 __global__ void inc_i32_kernel(int32_t* p, int32_t by) { if (threadIdx.x == 0) p[0] += by; }
@@ -766,13 +931,19 @@ extern "C" int tdvc_fill(float* y, float value, int64_t n, void* stream) {
 
 extern "C" int tdvc_cin_fwd(const float* x, const float* gb, float* y, float* mean, float* rstd, int B, int C, int T, int Tg, float eps, void* stream) {
   if (Tg != 1 && Tg != T) return tdvc_fail(TDVC_EINVAL, "cin_fwd: Tg must be 1 or T");
-  hipLaunchKernelGGL(cin_fwd_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, x, gb, y, mean, rstd, C, T, Tg, eps);
+  const bool al = (T & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)y) | ((uintptr_t)gb)) & 15) == 0;
+  if (al && T <= 4096) hipLaunchKernelGGL(cin_fwd_row_kernel<4>, dim3(C, B), dim3(256), 0, (hipStream_t)stream, x, gb, y, mean, rstd, C, T, Tg, eps);
+  else if (al && T <= 16384) hipLaunchKernelGGL(cin_fwd_row_kernel<16>, dim3(C, B), dim3(256), 0, (hipStream_t)stream, x, gb, y, mean, rstd, C, T, Tg, eps);
+  else hipLaunchKernelGGL(cin_fwd_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, x, gb, y, mean, rstd, C, T, Tg, eps);
   TDVC_CHECK_LAUNCH(); return TDVC_OK;
 }
 extern "C" int tdvc_cin_bwd(const float* x, const float* gb, const float* dy, const float* mean, const float* rstd,
                             float* dx, float* dgb, int B, int C, int T, int Tg, void* stream) {
   if (Tg != 1 && Tg != T) return tdvc_fail(TDVC_EINVAL, "cin_bwd: Tg must be 1 or T");
-  hipLaunchKernelGGL(cin_bwd_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, x, gb, dy, mean, rstd, dx, dgb, C, T, Tg);
+  const bool al = (T & 3) == 0 && ((((uintptr_t)x) | ((uintptr_t)dy) | ((uintptr_t)dx) | ((uintptr_t)gb) | ((uintptr_t)dgb)) & 15) == 0;
+  if (al && T <= 4096) hipLaunchKernelGGL(cin_bwd_row_kernel<4>, dim3(C, B), dim3(256), 0, (hipStream_t)stream, x, gb, dy, mean, rstd, dx, dgb, C, T, Tg);
+  else if (al && T <= 8192) hipLaunchKernelGGL(cin_bwd_row_kernel<8>, dim3(C, B), dim3(256), 0, (hipStream_t)stream, x, gb, dy, mean, rstd, dx, dgb, C, T, Tg);
+  else hipLaunchKernelGGL(cin_bwd_kernel, dim3(C, B), dim3(256), 0, (hipStream_t)stream, x, gb, dy, mean, rstd, dx, dgb, C, T, Tg);
   TDVC_CHECK_LAUNCH(); return TDVC_OK;
 }
 

@@ -132,8 +132,11 @@ class ArenaModule(nn.Module):
         if device.type != 'cuda':
             raise L.TdvcError('tdvc modules run on an MI355X device only (no CPU fallback): move inputs to cuda')
         ps = list(self.parameters())
-        if self._arena is not None and self._arena.device == device and self._arena.owns(ps[0]) and self._arena.owns(ps[-1]):
+        sig = tuple(p.requires_grad for p in ps)      # frozen sub-networks (requires_grad = False, train.py:195-197) change the arena layout
+        if (self._arena is not None and self._arena.device == device and self._arena.owns(ps[0]) and self._arena.owns(ps[-1]) and
+                getattr(self, '_arena_sig', None) == sig):
             return self._arena
+        self._arena_sig = sig
         L.lib()   # fail loudly before touching anything if the extension is missing
         tr = [name for name, m in self.named_modules()
               if isinstance(m, ConvParams) and m.wn and m.spec.kind == L.CONV and m.spec.stride == 1 and m.spec.groups == 1]

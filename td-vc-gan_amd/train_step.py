@@ -39,27 +39,22 @@ class StepConfig:
     weight_decay: float = 1e-2
     n_neg: int = 100
     fft_sizes: tuple = (2048, 1024, 512)
+    # loop switches that every shipped YAML leaves off; semantics = the reference's, file:line at each use
+    lambda_wave: float = 0.0            # train.py:357-360, 381-384: waveform L1 terms
+    lambda_converted: float = 0.0       # train.py:409-413: accepted, reaches no loss in the reference (see _g_fwd_bwd)
+    jitter_amp: int = 0                 # train.py:335-336: the real signal rolled by a random per-sample shift as the loss target
+    grad_max_norm_d: float = None       # train.py:289-290: clip_grad_norm_ on D before its optimizer step
+    grad_max_norm_g: float = None       # train.py:489-490
+    d_step_interval: int = 1            # train.py:259
+    g_step_interval: int = 1            # train.py:320
+    freeze_subnets: tuple = ()          # train.py:195-197: ('encoder',) -> G.encoder parameters get requires_grad = False
 
     @staticmethod
     def from_hparams(train: dict) -> 'StepConfig':
-        """Build from the `train` document of a reference YAML (config/*.yaml). Keys that change what is optimised and
-        that this path does not implement raise instead of being dropped silently; `lambda_f0` (the CREPE-backed F0 term,
-        train.py:429-470) is excluded by contract (torchcrepe is not available: SURVEY §8c) and only warns."""
+        """Build from the `train` document of a reference YAML (config/*.yaml). `lambda_f0` (the CREPE-backed F0 term,
+        train.py:429-470) is excluded by contract (torchcrepe is not available: SURVEY §8c) and only warns; a sub-network
+        name in `freeze_subnets` other than 'encoder' is ignored by the reference too (train.py:195)."""
         g = train.get
-        unsupported = {
-            'lambda_wave': (g('lambda_wave', 0) or 0) != 0,              # train.py:357-360, 381-384
-            'lambda_converted': bool(g('lambda_converted', 0)),          # train.py:409-413
-            'jitter_amp': (g('jitter_amp', 0) or 0) > 0,                 # train.py:335-336
-            'grad_max_norm_D': g('grad_max_norm_D') is not None,         # train.py:289-290
-            'grad_max_norm_G': g('grad_max_norm_G') is not None,         # train.py:489-490
-            'D_step_interval': (g('D_step_interval', 1) or 1) != 1,      # train.py:259
-            'G_step_interval': (g('G_step_interval', 1) or 1) != 1,      # train.py:320
-            'freeze_subnets': bool(g('freeze_subnets')),                 # train.py:195-197
-        }
-        bad = [k for k, v in unsupported.items() if v]
-        if bad:
-            raise NotImplementedError(f'train config keys not implemented on the HIP path: {bad} '
-                                      '(they change the objective / schedule; refusing to train something else silently)')
         if float(g('lambda_f0', 0) or 0) != 0:
             import warnings
             warnings.warn('lambda_f0 != 0: the CREPE-backed F0 loss term (train.py:429-470) is not part of this path '
@@ -70,7 +65,13 @@ class StepConfig:
                           lambda_corrupted=float(g('lambda_corrupted', 0)), lambda_latcls=float(g('lambda_latcls', 0)),
                           lambda_f0=float(g('lambda_f0', 0)),
                           lr_g=float(g('lr_g', 1e-4)), lr_d=float(g('lr_d', 1e-4)),
-                          betas=tuple(g('adam_beta', (0.8, 0.99))))
+                          betas=tuple(g('adam_beta', (0.8, 0.99))),
+                          lambda_wave=float(g('lambda_wave', 0) or 0), lambda_converted=float(g('lambda_converted', 0) or 0),
+                          jitter_amp=int(g('jitter_amp', 0) or 0),
+                          grad_max_norm_d=(float(g('grad_max_norm_D')) if g('grad_max_norm_D') is not None else None),
+                          grad_max_norm_g=(float(g('grad_max_norm_G')) if g('grad_max_norm_G') is not None else None),
+                          d_step_interval=int(g('D_step_interval', 1) or 1), g_step_interval=int(g('G_step_interval', 1) or 1),
+                          freeze_subnets=tuple(g('freeze_subnets') or ()))
 
 
 class TrainStep:
@@ -79,6 +80,10 @@ class TrainStep:
         self.reuse_fake = reuse_fake
         self.grad_sync = grad_sync            # parallel.GradSync or None
         self.comm_events = None               # set to [] to record (backward done, all-reduce joined) event pairs per optimizer step
+        self.iter_count = 0                   # train.py:211: the step intervals count iterations from 0
+        if 'encoder' in cfg.freeze_subnets:   # train.py:195-197
+            for p_ in G.encoder.parameters():
+                p_.requires_grad = False
         ga, da = G.ensure_arena(self.device), D.ensure_arena(self.device)
         self.opt_g = FlatAdamW(ga, cfg.lr_g, cfg.betas, cfg.eps, cfg.weight_decay)
         self.opt_d = FlatAdamW(da, cfg.lr_d, cfg.betas, cfg.eps, cfg.weight_decay)
@@ -137,7 +142,7 @@ class TrainStep:
             self.grad_sync.wait(arena)
 
     def _d_update(self):
-        self.opt_d.step(grad_scale=1.0 if self.grad_sync is None else self.grad_sync.scale)
+        self.opt_d.step(grad_scale=1.0 if self.grad_sync is None else self.grad_sync.scale, max_norm=self.cfg.grad_max_norm_d)
         self.D.arena.materialize()
 
     def _d_fwd_bwd(self, batch, log):
@@ -170,7 +175,7 @@ class TrainStep:
         self._g_update()
 
     def _g_update(self):
-        self.opt_g.step(grad_scale=1.0 if self.grad_sync is None else self.grad_sync.scale)
+        self.opt_g.step(grad_scale=1.0 if self.grad_sync is None else self.grad_sync.scale, max_norm=self.cfg.grad_max_norm_g)
         self.G.arena.materialize()
 
     def _g_fwd_bwd(self, batch, log, idx_x=None, idx_y=None):
@@ -181,11 +186,12 @@ class TrainStep:
         if self.C is not None:
             self.C.arena.wgrad_enabled = False            # the classifier's own grads from the G-step are dead work too
         try:
-            if self.reuse_fake:
+            if self.reuse_fake and getattr(self, '_gen_out', None) is not None:
                 (fake, fake_subs), idt_pair, emb_real, emb_cor = self._gen_out
                 self._gen_out = None
-            else:
+            else:       # reuse off, or no D-step ran in this iteration (D_step_interval > 1)
                 (fake, fake_subs), idt_pair, emb_real, emb_cor = self._generate(batch)
+                self._real_subs = D.get_subsamples(real)
             need_feat = c.lambda_idt > 0 and c.lambda_feat > 0
             separate_idt = need_feat and idt_pair is not None and idt_pair[0] is not fake
             want_rec = c.lambda_rec > 0 and not c.no_conv
@@ -235,10 +241,22 @@ class TrainStep:
             adv = LS.lsgan_loss(out_fake, 1.0, rng=adv_rng)
             total = adv
             log['G_loss_adv_fake'] = adv.detach()
+            # loss target of the reconstruction / identity terms: the real signal, rolled by a random per-sample shift when
+            # jitter_amp > 0 (train.py:333-341, util.audio.add_jitter; the draw comes in as batch['jitter'] for reproducible runs)
+            real_t, real_t_subs = real, self._real_subs
+            if c.jitter_amp > 0 and (c.lambda_rec > 0 or c.lambda_idt > 0):
+                shifts = batch.get('jitter')
+                if shifts is None:
+                    shifts = torch.randint(-c.jitter_amp, c.jitter_amp + 1, (B,), device=real.device)
+                real_t = torch.empty_like(real)
+                LS.L.check(LS.L.lib().tdvc_roll_batches(real.data_ptr(), shifts.to(torch.int64).contiguous().data_ptr(), real_t.data_ptr(), B, real.shape[1],
+                                                    real.shape[2], torch.cuda.current_stream(real.device).cuda_stream))
+                real_t_subs = D.get_subsamples(real_t) if c.lambda_feat > 0 else None
             feats_real = None
             if (need_feat and idt is not None) or feats_rec is not None:
                 with torch.no_grad():                      # Q6: D(real) feature maps are only ever used detached
-                    _, feats_real = D(real, batch['label_src'], self._real_subs, views=True)
+                    _, feats_real = D(real_t, batch['label_src'], real_t_subs, views=True)
+            wave_idt = None
             if want_rec:                                   # train.py:344-361
                 l_rec = None
                 if feats_rec is not None:
@@ -246,9 +264,13 @@ class TrainStep:
                     log['G_loss_rec_feat'] = l_rf.detach()
                     l_rec = c.lambda_feat * l_rf
                 if c.lambda_spec > 0:
-                    l_rs = LS.multiscale_spec_loss(rec, real, list(c.fft_sizes))
+                    l_rs = LS.multiscale_spec_loss(rec, real_t, list(c.fft_sizes))
                     log['G_loss_rec_spec'] = l_rs.detach()
                     l_rec = c.lambda_spec * l_rs if l_rec is None else l_rec + c.lambda_spec * l_rs
+                if c.lambda_wave > 0:                      # train.py:357-360: mean |real - rec| on the un-jittered signal
+                    l_rw = LS.multiscale_feat_loss([[rec]], [[real]], norm_p=1)
+                    log['G_loss_rec_wave'] = l_rw.detach()
+                    l_rec = c.lambda_wave * l_rw if l_rec is None else l_rec + c.lambda_wave * l_rw
                 if l_rec is not None:
                     log['G_loss_rec'] = l_rec.detach()
                     total = total + c.lambda_rec * l_rec
@@ -259,12 +281,22 @@ class TrainStep:
                     log['G_loss_idt_feat'] = l_feat.detach()
                     l_idt = c.lambda_feat * l_feat
                 if c.lambda_spec > 0:
-                    l_spec = LS.multiscale_spec_loss(idt, real, list(c.fft_sizes))
+                    l_spec = LS.multiscale_spec_loss(idt, real_t, list(c.fft_sizes))
                     log['G_loss_idt_spec'] = l_spec.detach()
                     l_idt = c.lambda_spec * l_spec if l_idt is None else l_idt + c.lambda_spec * l_spec
+                if c.lambda_wave > 0:
+                    # train.py:381-384 adds the identity waveform term to g_loss_REC (`g_loss_rec += ...`), so it enters the total
+                    # with the weight lambda_rec * lambda_wave -- reproduced as is (zero weight when lambda_rec == 0)
+                    wave_idt = LS.multiscale_feat_loss([[idt]], [[real]], norm_p=1)
+                    log['G_loss_idt_wave'] = wave_idt.detach()
                 if l_idt is not None:
                     log['G_loss_idt'] = l_idt.detach()
                     total = total + c.lambda_idt * l_idt
+            if wave_idt is not None and c.lambda_rec != 0:
+                total = total + (c.lambda_rec * c.lambda_wave) * wave_idt
+            # lambda_converted (train.py:409-413): the reference encodes the converted signal and computes a contrastive term, but
+            # accumulates it into itself (`g_loss_cont_emb_conv += g_loss_cont_emb_conv`), never into g_loss_cont_emb: it reaches no
+            # loss and no gradient. Nothing to compute here.
             if self.C is not None:      # train.py:420-422, :480 -- gradient-reversed into the encoder
                 l_cls = LS.cross_entropy_loss(self.C(emb_real), batch['label_src'])
                 log['G_loss_lat_cls'] = l_cls.detach()
@@ -284,10 +316,17 @@ class TrainStep:
     def run(self, batch, idx_x=None, idx_y=None):
         """One iteration. Returns {tag: 1-element device tensor}; no host synchronisation inside."""
         log = {}
-        self.d_step(batch, log)
-        if self.C is not None:
-            self.c_step(batch, log)
-        self.g_step(batch, log, idx_x, idx_y)
+        c, it = self.cfg, self.iter_count
+        self.iter_count += 1
+        do_d, do_g = it % c.d_step_interval == 0, it % c.g_step_interval == 0      # train.py:259, :320
+        self._gen_out = None
+        if do_d:
+            self.d_step(batch, log)
+            if self.C is not None:      # the classifier step sits inside the D-step block (train.py:298-308)
+                self.c_step(batch, log)
+        if do_g:
+            self.g_step(batch, log, idx_x, idx_y)
+        self._gen_out = None
         return log
 
     def c_step(self, batch, log):
@@ -314,6 +353,10 @@ class TrainStep:
         (72.5 vs 72.2 ms, `bench.py --force-dp --no-graph`), i.e. it is not host-bound."""
         if self.grad_sync is not None:
             raise RuntimeError('graph capture is single-GPU only; run data-parallel steps eagerly')
+        if self.cfg.d_step_interval != 1 or self.cfg.g_step_interval != 1:
+            raise RuntimeError('graph capture needs D_step_interval = G_step_interval = 1 (iterations would differ in their work)')
+        if self.cfg.jitter_amp > 0 and 'jitter' not in batch:
+            raise RuntimeError("graph capture with jitter_amp > 0 needs the shifts as a static input: batch['jitter'] (int64 [B])")
         dev = self.device
         side = torch.cuda.Stream(dev)
         side.wait_stream(torch.cuda.current_stream(dev))
