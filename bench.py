@@ -37,6 +37,10 @@ def parse_args():
     ap.add_argument('--seconds', type=float, default=1.0, help='length of each sample in seconds (BASELINE config #5: 2)')
     ap.add_argument('--config', default='conv_enc-stage1', help='conv_enc-stage1 | conv_enc-stage2_1 | conv_enc-stage2_2 | wavlm-stage2_2 (frozen SSL '
                                                                 "extractor = synth.FrameFeatureExtractor, the stand-in for WavLM-Large whose checkpoint is absent)")
+    ap.add_argument('--ssl-extractor', default='wavlm-shape', choices=['wavlm-shape', 'frame'],
+                    help="wavlm-* configs: the frozen extractor stand-in: 'wavlm-shape' = synth.WavLMShapedExtractor (stock torch.nn modules with "
+                         "WavLM-Large's compute shape: 7 strided convs to 512 ch + 24 transformer layers 1024/16/4096, ~315 M parameters, random "
+                         "init), 'frame' = the one-conv synth.FrameFeatureExtractor of the parity tests")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-table', action='store_true')
     ap.add_argument('--no-graph', action='store_true', help='run eagerly instead of replaying a captured hipGraph')
@@ -367,7 +371,7 @@ def cpu_model():
     return 'unknown'
 
 
-def cpu_baseline(pkg, cfg_train, iters=3, sd_g=None, ssl=False):
+def cpu_baseline(pkg, cfg_train, iters=3, sd_g=None, ssl=False, extractor=None):
     """CPU oracle timed on this host: B=2 x 1 s, 1 warm-up + `iters` timed iterations (~10-30 s)."""
     import torch
     sys.path.insert(0, os.path.join(ROOT, 'tests'))
@@ -376,7 +380,7 @@ def cpu_baseline(pkg, cfg_train, iters=3, sd_g=None, ssl=False):
     cores = usable_cores()
     torch.set_num_threads(cores)
     cfg = OS.StepConfig.from_hparams(cfg_train)
-    st = OS.TrainStep(sd_g if sd_g is not None else filled_sd('G'), filled_sd('D'), cfg, ssl_extractor=pkg.synth.FrameFeatureExtractor() if ssl else None)
+    st = OS.TrainStep(sd_g if sd_g is not None else filled_sd('G'), filled_sd('D'), cfg, ssl_extractor=(extractor if extractor is not None else pkg.synth.FrameFeatureExtractor()) if ssl else None)
     B, T = 2, SR
     bt = pkg.synth.make_batch(B, T, seed=1234, conversion=not cfg.no_conv)
     ix, iy = pkg.synth.contrastive_indices(B, T // 320, cfg.n_neg, 1), pkg.synth.contrastive_indices(B, T // 320, cfg.n_neg, 2)
@@ -448,8 +452,10 @@ def main():
         cfg = pkg.train_step.StepConfig.from_hparams(hp.train)
     ssl = args.config.startswith('wavlm')
     sd_g = None
+    extractor = None
     if ssl:
-        G, D, sd_g = build_ssl_models(dev)
+        extractor = pkg.synth.WavLMShapedExtractor() if args.ssl_extractor == 'wavlm-shape' else pkg.synth.FrameFeatureExtractor()
+        G, D, sd_g = build_ssl_models(dev, extractor)
     else:
         G, D = build_models(dev)
     sync = pkg.parallel.GradSync() if dp else None
@@ -541,14 +547,37 @@ def main():
                    steps=args.steps, warmup=args.warmup, ms_per_step=step_ms, higher_is_better=True,
                    scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
                    config=dict(workload=f'config/{args.config}.yaml full D+G iteration, {B} x {args.seconds:g} s @16 kHz per GPU, NUM_SPK=16, '
-                                        'F0 (CREPE) loss term excluded' + (', frozen SSL extractor = synthetic stand-in for WavLM-Large '
-                                                                           '(plain PyTorch, inside the timed step)' if ssl else ''),
+                                        'F0 (CREPE) loss term excluded' + ((', frozen SSL extractor = ' + ('stock-torch.nn stand-in with WavLM-Large\'s compute '
+                                                                           'shape (7 strided convs + 24 transformer layers 1024/16/4096, random init)'
+                                                                           if args.ssl_extractor == 'wavlm-shape' else 'one-conv synthetic stand-in') +
+                                                                           ', plain PyTorch-ROCm, inside the timed step') if ssl else ''),
                                global_batch=world * B, parallelism=f'dp{world}'),
                    final_G_loss=g_loss, launch=launch, ms_per_step_median=ms_median,
                    timing='value / ms_per_step: K steps between two device synchronisations (the contract); ms_per_step_median: median of the K '
                           'per-step HIP-event timings inside that region')
         if dp_info is not None:
             out['data_parallel'] = dp_info
+        if ssl:
+            # how much of the step is the frozen extractor (plain PyTorch-ROCm, not this repo's code)? One iteration calls it on
+            # [real; corrupted] (2B signals) and, with the cycle branch, on the converted signal (B signals): model/ssl_encoder.py:141-145
+            with torch.no_grad():
+                pads = [torch.nn.functional.pad(torch.cat([bt['signal_real'], bt['signal_corrupted']], 0), (160, 0)).squeeze(1)]
+                if cfg.lambda_rec > 0 and not cfg.no_conv:
+                    pads.append(torch.nn.functional.pad(bt['signal_real'], (160, 0)).squeeze(1))
+                def ext_once():
+                    for w_ in pads:
+                        G.encoder.cmodel.extract_features(w_)
+                for _ in range(3):
+                    ext_once()
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                torch.cuda.synchronize(); e0.record()
+                for _ in range(10):
+                    ext_once()
+                e1.record(); torch.cuda.synchronize()
+            ext_ms = e0.elapsed_time(e1) / 10
+            out['ssl_extractor'] = dict(kind=args.ssl_extractor, parameters=sum(p.numel() for p in G.encoder.cmodel.parameters()),
+                                        extractor_ms_per_step=ext_ms, hip_path_ms_per_step=step_ms - ext_ms,
+                                        how='extractor calls of one iteration timed on their own (HIP events, 10 repeats); hip_path = step - extractor')
         if classes is not None:      # rank 0 of a multi-rank run goes straight to the JSON line
             table, north = kernel_table(pkg, dev, classes, step_ms)
             try:
@@ -579,7 +608,7 @@ def main():
             roof['share_weighted_frac'] = {k: dict(share_of_step=v[0], mean_frac_of_peak=v[1] / max(v[0], 1e-12)) for k, v in by.items()}
             out['roofline'] = roof
         if world == 1 and not args.no_cpu_baseline:
-            out['cpu_baseline'] = cpu_baseline(pkg, hp.train, sd_g=sd_g, ssl=ssl)
+            out['cpu_baseline'] = cpu_baseline(pkg, hp.train, sd_g=sd_g, ssl=ssl, extractor=((pkg.synth.WavLMShapedExtractor() if args.ssl_extractor == 'wavlm-shape' else pkg.synth.FrameFeatureExtractor()) if ssl else None))
             out['speedup_vs_cpu'] = value / out['cpu_baseline']['value']
         print(json.dumps(out), flush=True)
     if dp:

@@ -194,3 +194,47 @@ class FrameFeatureExtractor(torch.nn.Module):
         # gain: the training signals sit at -30 dB RMS; bring the frames to O(1) before the squashing non-linearity
         f = torch.tanh(torch.nn.functional.conv1d(wave[:, None, :].float() * 30.0, self.weight, stride=self.hop))
         return (f.transpose(1, 2).contiguous(),)
+
+
+class WavLMShapedExtractor(torch.nn.Module):
+    """Frozen stand-in with the COMPUTE SHAPE of WavLM-Large (wavlm/WavLM.py in the reference; checkpoint not shipped), built
+    from stock torch.nn modules only, for timing BASELINE config #5 (`wavlm-stage2_2`): a 7-layer strided conv front end to 512
+    channels (kernels 10,3,3,3,3,2,2 / strides 5,2,2,2,2,2,2: hop 320, receptive field 400, layer-norm + GELU after each conv),
+    LayerNorm + projection to 1024, a grouped positional conv (k 128, 16 groups), 24 pre-norm transformer layers (1024 wide,
+    16 heads, 4096 FFN) and a final LayerNorm -- ~315 M parameters, random init, eval mode, no gradient. Same interface and
+    framing as the module the reference calls (model/ssl_encoder.py:141-145): extract_features(wave [B, L]) -> ([B, L', 1024],).
+    Not WavLM: no relative position bias / gating (a few percent of its FLOPs), random weights -> throughput only, no parity
+    claim on the features."""
+
+    def __init__(self, layers: int = 24, dim: int = 1024, heads: int = 16, ffn: int = 4096, seed: int = 20240):
+        super().__init__()
+        nn = torch.nn
+        with torch.random.fork_rng(devices=[]):
+            torch.manual_seed(seed)
+            specs = [(10, 5)] + [(3, 2)] * 4 + [(2, 2)] * 2
+            convs, norms, cin = [], [], 1
+            for k, st in specs:
+                convs.append(nn.Conv1d(cin, 512, k, st, bias=False)); norms.append(nn.LayerNorm(512)); cin = 512
+            self.convs, self.norms = nn.ModuleList(convs), nn.ModuleList(norms)
+            self.post_norm = nn.LayerNorm(512)
+            self.proj = nn.Linear(512, dim)
+            self.pos_conv = nn.Conv1d(dim, dim, 128, padding=64, groups=16)
+            self.layers = nn.ModuleList([nn.TransformerEncoderLayer(dim, heads, ffn, dropout=0.0, activation='gelu', batch_first=True,
+                                                                    norm_first=True) for _ in range(layers)])
+            self.final_norm = nn.LayerNorm(dim)
+        for p_ in self.parameters():
+            p_.requires_grad = False
+        self.eval()
+
+    @torch.no_grad()
+    def extract_features(self, wave: torch.Tensor):
+        F = torch.nn.functional
+        x = wave[:, None, :].float() * 30.0            # the training signals sit at -30 dB RMS
+        for conv, norm in zip(self.convs, self.norms):
+            x = F.gelu(norm(conv(x).transpose(1, 2)).transpose(1, 2))
+        x = self.proj(self.post_norm(x.transpose(1, 2)))                    # [B, L', 1024]
+        pos = F.gelu(self.pos_conv(x.transpose(1, 2))[:, :, :x.shape[1]]).transpose(1, 2)
+        x = x + pos
+        for layer in self.layers:
+            x = layer(x)
+        return (self.final_norm(x).contiguous(),)

@@ -37,12 +37,13 @@ def build_models(dev):
     return G, D
 
 
-def build_ssl_models(dev):
+def build_ssl_models(dev, extractor=None):
     """Generator(encoder_model='wavlm') with the stand-in frozen extractor + the shipped discriminator; returns the
-    state_dict of everything but the extractor (deterministic fill, like build_models)."""
+    state_dict of everything but the extractor (deterministic fill, like build_models). extractor: the frozen module to inject
+    (default synth.FrameFeatureExtractor, the small one the parity tests use on both sides)."""
     P = pkg()
     G = P.modules.Generator(**{**G_ARGS, 'encoder_model': 'wavlm', 'decoder_channels': list(G_ARGS['decoder_channels']),
-                               'cmodel': P.synth.FrameFeatureExtractor()})
+                               'cmodel': extractor if extractor is not None else P.synth.FrameFeatureExtractor()})
     D = P.modules.CollaborativeMultibandDiscriminator(**D_ARGS)
     enc_shapes = json.load(open(os.path.join(GOLDEN, 'shapes_SSLENC.json')))
     sd = {k: v for k, v in filled_sd('G').items() if not k.startswith('encoder.')}
