@@ -17,6 +17,8 @@ messages (8 MiB segments; 68 MB of D gradients = 8 calls) rather than per-tensor
 
 One process per GPU, torch.distributed backend "nccl" (= RCCL on ROCm) or "gloo" (CPU tests).
 """
+import os
+
 import torch
 import torch.distributed as dist
 
@@ -31,6 +33,12 @@ class GradSync:
         self.bucket = max(1, bucket_bytes // 4)
         self._side = None
         self.calls = 0            # collectives issued (tests / diagnostics)
+        # Diagnostic for one-GPU boxes (TDVC_DP_LOOPBACK=1, world size 1 only): RCCL launches NO kernel for a single-rank
+        # all-reduce, so a kernel trace cannot show where the exchange sits. With the switch every segment hand-over also
+        # copies the segment to a scratch buffer on the side stream -- a stand-in with the all-reduce's bytes and stream
+        # position -- so that the trace shows side-stream work under the backward kernels. Never changes G.
+        self.loopback = os.environ.get('TDVC_DP_LOOPBACK') == '1' and self.world == 1
+        self._scratch = None
 
     # ------------------------------------------------------------------ segment pipeline (product path)
     def attach(self, arena):
@@ -39,7 +47,11 @@ class GradSync:
 
     def _side_stream(self, device):
         if self._side is None:
-            self._side = torch.cuda.Stream(device)
+            # a HIGH-PRIORITY stream: HIP multiplexes the streams of a process onto a few hardware queues, and a plain side
+            # stream can land on the compute stream's queue, where its kernels run strictly in turn with the backward pass
+            # (seen in the kernel trace of `bench.py --force-dp`: profiles/r03_dp_overlap.txt); priority streams get
+            # hardware queues of their own, so the exchange really runs beside the compute kernels
+            self._side = torch.cuda.Stream(device, priority=-1)
         return self._side
 
     def reduce_segment(self, arena, seg):
@@ -52,6 +64,10 @@ class GradSync:
             side.wait_stream(torch.cuda.current_stream(flat.device))
             with torch.cuda.stream(side):
                 dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
+                if self.loopback:
+                    if self._scratch is None or self._scratch.numel() < flat.numel():
+                        self._scratch = torch.empty(flat.numel(), dtype=flat.dtype, device=flat.device)
+                    self._scratch[:flat.numel()].copy_(flat)
         else:
             dist.all_reduce(flat, op=dist.ReduceOp.SUM, group=self.group)
 
