@@ -335,7 +335,7 @@ def kernel_table(pkg, dev, classes, step_ms, iters=20, manifest=None, only_ops=N
     # the kernel the north star names: the stride-1 dilated Conv1d 16 -> 16 k3 (HBM-bound end of the trunk). In the step it runs
     # inside the fused FiLM-block forward; the stand-alone conv launch (which the step no longer issues for these blocks) stays
     # next to it as the un-fused per-conv figure of SURVEY §8(d)
-    BL = max((rec[2] for rec in classes if rec[0] == 'fwd'), default=32)
+    BL = max((rec[1] for rec in classes if rec[0] == 'film_block_fwd'), default=32)      # the generator's trunk batch ([cond 0; cond 1])
     alone = conv_class(('fwd', (16, 16, 3, 1, 1, 1, 1, 1, 0, 0, 0, 0), BL, 16000, L.XF_LRELU, 0, False, False, True, False, False), 0)
     keep.clear()
     torch.cuda.empty_cache()
