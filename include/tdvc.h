@@ -135,7 +135,7 @@ void tdvc_fold_reset(void* stream);
  *   instantiations launched; tdvc_debug_trace_dump copies them ('\n'-separated, NUL-terminated) and returns the size needed. */
 void tdvc_set_force_generic(int on);
 void tdvc_debug_force_tile(int cfg);
-void tdvc_debug_knob(int which, int value); /* tuning knobs for A/B measurements: 0 = XCD-aware block order of the lean conv kernel (1 = on; default 0: measured null on this path); 3 = one block per CU in the fused conditioning backward (diagnostic); 4 = 1: no sample folding of short sequences (T = 16 / 32) in the lean conv kernel */
+void tdvc_debug_knob(int which, int value); /* tuning knobs for A/B measurements: 0 = XCD-aware block order of the lean conv kernel (1 = on; default 0: measured null on this path); 3 = one block per CU in the fused conditioning backward (diagnostic); 4 = 1: no sample folding of short sequences (T = 16 / 32) in the lean conv kernel; 5 = 1: exact-fp32 MFMA instead of the split-bf16 x6 weight-grad kernel (conv_wgrad_x6.hip) */
 void tdvc_debug_lds_cap(int bytes);   /* tuning knob: LDS bytes per block the lean kernel's chunk-size choice may use (0 = built-in) */
 void tdvc_debug_trace(int on);
 size_t tdvc_debug_trace_dump(char* buf, size_t cap);

@@ -291,13 +291,30 @@ static bool wgrad_lean_ok(const tdvc_conv_desc* d) {
          (d->Tout > 128 || wide) && wgrad_lean_supported(d->K, d->dilation) && (d->K != 15 || d->Cout <= 16 || d->Cin <= 16);
 }
 
-namespace tdvc { int wgrad_lean_nslab(int R, int Cin, int N, int K, int B); }
+namespace tdvc {
+int wgrad_lean_nslab(int R, int Cin, int N, int K, int B);
+bool wgrad_x6_ok(int R, int Cin, int T, int K, int dil, int pad, int reflect);
+void wgrad_x6_plan(int R, int T, int B, int* ntiles, int* tpb, int* ngroups);
+hipError_t launch_conv_wgrad_x6(const WgLeanP& q, int B, hipStream_t st);
+}
+// split-bf16 weight-grad kernel (conv_wgrad_x6.hip): the layer geometry it takes
+static bool wgrad_x6_desc_ok(const tdvc_conv_desc* d) {
+  return !g_force_generic && d->kind == TDVC_CONV && d->stride == 1 && d->groups == 1 && d->Tin == d->Tout && d->w_cin == 0 &&
+         wgrad_x6_ok(d->Cout, d->Cin, d->Tout, d->K, d->dilation, d->pad, d->reflect);
+}
 
 extern "C" size_t tdvc_conv_wgrad_workspace(const tdvc_conv_desc* d) {
   if (check_desc(d)) return 0;
   size_t small = small_group_ok(d) ? small_group_wgrad_workspace(d->B, d->groups, d->K) : 0;
   if (wgrad_lean_ok(d)) {
-    return (size_t)wgrad_lean_nslab(d->Cout, d->Cin, d->Tout, d->K, d->B) * ((size_t)d->Cout * d->Cin * d->K + d->Cout) * sizeof(float);
+    size_t lean = (size_t)wgrad_lean_nslab(d->Cout, d->Cin, d->Tout, d->K, d->B) * ((size_t)d->Cout * d->Cin * d->K + d->Cout) * sizeof(float);
+    if (wgrad_x6_desc_ok(d)) {       // which of the two kernels runs depends on the operand transforms: size for either
+      int nt, tpb, ng;
+      wgrad_x6_plan(d->Cout, d->Tout, d->B, &nt, &tpb, &ng);
+      const size_t x6 = (size_t)ng * ((size_t)d->Cout * d->Cin * d->K + d->Cout) * sizeof(float);
+      if (x6 > lean) lean = x6;
+    }
+    return lean;
   }
   WgradP p = {};
   fill_wgrad(d, nullptr, p);
@@ -330,6 +347,26 @@ extern "C" int tdvc_conv_wgrad(const tdvc_conv_desc* d, const tdvc_conv_wgrad_ar
     if (e == hipSuccess) return TDVC_OK;
     if (e != hipErrorNotSupported) return tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));
     e = hipSuccess;
+  }
+  auto unit_scale = [](float sc) { return sc == 0.f || sc == 1.f; };
+  if (a->dw && wgrad_lean_ok(d) && wgrad_x6_desc_ok(d) && a->x_xf.kind <= TDVC_XF_LRELU && a->dy_xf.kind == TDVC_XF_NONE &&
+      unit_scale(a->x_xf.scale) && unit_scale(a->dy_xf.scale) && (a->x_xf.kind == TDVC_XF_NONE || (a->x_xf.slope > 0.f && a->x_xf.slope <= 1.f)) &&
+      al16(a->x) && al16(a->dy) && (a->x_bs & 3) == 0 && (a->dy_bs & 3) == 0) {
+    // 3-tap conv with 65..144 input channels (FiLM cond_var.2): the split-bf16 x6 kernel, dy and x read once per 32-row block
+    WgLeanP q = {};
+    q.a = p.a; q.x = p.x; q.R = d->Cout; q.Cin = d->Cin; q.N = d->Tout;
+    int nt, tpb, nslab;
+    wgrad_x6_plan(d->Cout, d->Tout, d->B, &nt, &tpb, &nslab);
+    const long sstride = wsize + d->Cout;
+    const size_t need = (size_t)nslab * (size_t)sstride * sizeof(float);
+    if (!a->workspace || a->workspace_bytes < need) return tdvc_fail(TDVC_EWORKSPACE, "conv_wgrad: workspace too small");
+    q.slab = (float*)a->workspace; q.slab_stride = sstride; q.bias_off = a->dbias ? wsize : -1;
+    e = launch_conv_wgrad_x6(q, d->B, st);
+    if (e != hipSuccess) return tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));
+    const int rowlen = d->Cin * d->K;
+    e = launch_slab_reduce(q.slab, nslab, sstride, a->dbias ? sstride : wsize, a->dw, rowlen, rowlen, st, wsize, a->dbias);
+    if (e != hipSuccess) return tdvc_fail(TDVC_ELAUNCH, hipGetErrorString(e));
+    return TDVC_OK;
   }
   if (a->dw && wgrad_lean_ok(d)) {
     WgLeanP q = {};

@@ -225,6 +225,35 @@ def test_folded_short_sequences(case, B, dev):
     assert max(errs1.values()) < TOL, errs1
 
 
+# ------------------------------------------------------------------------------------------------ split-bf16 x6 weight-grad
+# conv_wgrad_x6_kernel: the weight gradient of 3-tap convs with 65..144 input channels (FiLM cond_var.2) on the bf16 matrix pipe
+# at fp32 accuracy (three exact bf16 pieces per operand, six piece products). Same 2e-5 bar against float64 as the exact-fp32
+# kernels, at ragged shapes (T not a multiple of the 32-step chunk, channel counts off the 16-tile grid, bias on / off through the
+# conv cases' bias gradient) and at the step's launch shapes; knob 5 runs the exact-fp32 MFMA kernel on the same case.
+X6_CASES = [(('x6_cond2_136_32_T500', 136, 32, 3, 1, 1, 1, 1, False, False, 500, 1, 0), 3),
+            (('x6_72_96_T260', 72, 96, 3, 1, 1, 1, 1, False, False, 260, 0, 0), 2),
+            (('x6_144_64_T2048', 144, 64, 3, 1, 1, 1, 1, False, False, 2048, 1, 0), 2),
+            (('x6_cond2_136_32_T16000', 136, 32, 3, 1, 1, 1, 1, False, False, 16000, 1, 0), 32),
+            (('x6_cond2_136_256_T500', 136, 256, 3, 1, 1, 1, 1, False, False, 500, 1, 0), 32)]
+
+
+@pytest.mark.parametrize('case,B', X6_CASES, ids=[c[0][0] for c in X6_CASES])
+def test_split_bf16_x6_weight_grad(case, B, dev):
+    with traced() as tr:
+        errs = OPS.conv_case_errors(case, dev, 0, B=B)
+    assert max(errs.values()) < TOL, (errs, sorted(tr.names))
+    assert 'conv_wgrad_x6_kernel' in tr.names, sorted(tr.names)
+    lib = importlib.import_module('td-vc-gan_amd')._lib.lib()
+    lib.tdvc_debug_knob(5, 1)                          # exact-fp32 MFMA path on the same case
+    try:
+        with traced() as tr1:
+            errs1 = OPS.conv_case_errors(case, dev, 0, B=B)
+    finally:
+        lib.tdvc_debug_knob(5, 0)
+    assert max(errs1.values()) < TOL and 'conv_wgrad_x6_kernel' not in tr1.names, (errs1, sorted(tr1.names))
+    assert errs['dw'] <= 4 * errs1['dw'] + 1e-7, (errs['dw'], errs1['dw'])      # not worse than the fp32 kernel's own rounding
+
+
 # ------------------------------------------------------------------------------------------------ sign-bit masks
 # tdvc_conv_fwd_args.sign_bits / tdvc_conv_dgrad_args.x_sign_bits: the forward epilogue packs (y > 0) into one bit per element,
 # the LeakyReLU-mask epilogue of the next layer's input-grad reads those words instead of the fp32 tensor (FiLM conditioning:

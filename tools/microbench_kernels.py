@@ -23,7 +23,8 @@ def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--iters', type=int, default=6)
     ap.add_argument('--batch', type=int, default=16)
-    ap.add_argument('--top', type=int, default=0, help='restrict the timed / profiled table to the N largest classes (0 = all)')
+    ap.add_argument('--top', type=int, default=0, help='selection run: write the N largest table entries (by a quick timing pass) to --ops-file and exit')
+    ap.add_argument('--ops-file', default=os.path.join(ROOT, 'gpurun_out', 'pmc_ops.json'), help='restrict the table to the entries listed in this JSON file (if it exists)')
     ap.add_argument('--manifest', default=os.path.join(ROOT, 'gpurun_out', 'pmc_manifest.json'))
     a = ap.parse_args()
     dev = torch.device('cuda:0')
@@ -38,13 +39,17 @@ def main():
     ix = pkg.synth.contrastive_indices(a.batch, 50, 100, 17).to(dev); iy = pkg.synth.contrastive_indices(a.batch, 50, 100, 917).to(dev)
     ts.run(bt, ix, iy)
     classes = bench.record_launches(pkg, lambda: ts.run(bt, ix, iy))
-    if a.top:      # PMC passes: only the classes that matter (by a quick timing pass), in a deterministic order
-        rows0, _ = bench.kernel_table(pkg, dev, classes, 1.0, iters=4)
-        keep_ops = {e['op'] for e in sorted(rows0, key=lambda e: -e['ms_per_launch'] * e['launches_per_step'])[:a.top]}
     del ts, G, D
     torch.cuda.empty_cache()
+    if a.top:      # selection run (NOT under the profiler): the classes that matter by a quick timing pass -> --ops-file, then exit
+        rows0, _ = bench.kernel_table(pkg, dev, classes, 1.0, iters=4)
+        ops_sel = [e['op'] for e in sorted(rows0, key=lambda e: -e['ms_per_launch'] * e['launches_per_step'])[:a.top]]
+        json.dump(ops_sel, open(a.ops_file, 'w'), indent=1)
+        print(f'{len(ops_sel)} table entries selected -> {a.ops_file}')
+        return
+    keep_ops = set(json.load(open(a.ops_file))) if a.ops_file and os.path.exists(a.ops_file) else None
     manifest = []
-    rows, _ = bench.kernel_table(pkg, dev, classes, 1.0, iters=a.iters, manifest=manifest, only_ops=keep_ops if a.top else None)
+    rows, _ = bench.kernel_table(pkg, dev, classes, 1.0, iters=a.iters, manifest=manifest, only_ops=keep_ops)
     os.makedirs(os.path.dirname(a.manifest), exist_ok=True)
     json.dump(manifest, open(a.manifest, 'w'), indent=1)
     for e in sorted(rows, key=lambda e: -e['ms_per_launch'] * e['launches_per_step']):
