@@ -249,6 +249,28 @@ def kernel_table(pkg, dev, classes, step_ms, iters=20, manifest=None, only_ops=N
         flops = 2.0 * B * (tin if transposed else tout) * cout * (cin // groups) * k
         return add(_conv_label(op, key, B, tin, ', '.join(extra)), n, alg, flops, calls, bufs.bytes_per_rotation)
 
+    def fwd_x6_class(rec, n):
+        """Split-bf16 x6 forward of a 3-tap conv (conv_fwd_x6.hip): same algorithmic bytes / flops as the fp32 launch it replaces."""
+        _, key, B, tin, xk, has_bias = rec
+        cin, cout = key[0], key[1]
+        spec = ops.ConvSpec(cin, cout, 3, 1, 1, 1, 1, False)
+        w = torch.randn(cout, cin, 3, device=dev) / (cin * 3) ** 0.5
+        b = torch.randn(cout, device=dev) * 0.1
+        spec.slot = arena.ConvSlot(w.data_ptr(), b.data_ptr() if has_bias else 0, 0, 0, True, None, 0)
+        bufs = Bufs(torch, dev, dict(x=(B, cin, tin), y=(B, cout, tin)))
+        planes = ops._weight_planes_x6(spec, dev)
+        st = torch.cuda.current_stream(dev).cuda_stream
+        d = spec.desc(B, tin)
+        calls, args = [], []
+        for s in bufs.sets:
+            a = L.ConvFwdArgs(s['x'].data_ptr(), s['x'].stride(0), ops._xf(xk), w.data_ptr(), b.data_ptr() if has_bias else None, None, 0, 0, 0.2, 1.0, None, 0,
+                              s['y'].data_ptr(), s['y'].stride(0), None, None, 0)
+            args.append(a)
+            calls.append(lambda a=a: L.check(lib.tdvc_conv_fwd_x6(C.byref(d), C.byref(a), planes.data_ptr(), st)))
+        keep[:] = [w, b, bufs, planes, args, spec, d]
+        label = _conv_label('fwd', key, B, tin, ('LeakyReLU on load, ' if xk == L.XF_LRELU else '') + 'split-bf16 x6 MFMA, fp32 accumulate')
+        return add(label, n, 4.0 * B * tin * (cin + cout) + 4.0 * (w.numel() + cout), 2.0 * B * tin * cin * cout * 3, calls, bufs.bytes_per_rotation)
+
     def film_block_class(rec, n):
         """The fused FiLM-block forward (film_block.hip): dilated Conv1d + FiLM + 1x1 conv + residual in one launch."""
         _, Bc, T, k, d, has_gb, has_acc = rec
@@ -323,7 +345,7 @@ def kernel_table(pkg, dev, classes, step_ms, iters=20, manifest=None, only_ops=N
         return add(f'FiLM cond_var.0 backward (dexc + dW window + dk3) 136ch T={T} B={Bc} (+ slab fold)', n, 4.0 * Bc * T * (nc + 2 * nv),
                    2.0 * Bc * T * nc * nv * 3 * 2, calls, bufs.bytes_per_rotation)
 
-    handlers = dict(fwd=conv_class, dgrad=conv_class, wgrad=conv_class, film_block_fwd=film_block_class, film_cond_bwd=cond_bwd_class,
+    handlers = dict(fwd=conv_class, dgrad=conv_class, wgrad=conv_class, fwd_x6=fwd_x6_class, film_block_fwd=film_block_class, film_cond_bwd=cond_bwd_class,
                     film_cond0_bwd=cond0_bwd_class)
     north = None
     for rec, n in sorted(classes.items(), key=lambda kv: str(kv[0])):

@@ -110,6 +110,14 @@ typedef struct {
 } tdvc_conv_wgrad_args;
 
 int tdvc_conv_fwd(const tdvc_conv_desc* d, const tdvc_conv_fwd_args* a, void* stream);
+/* Split-bf16 x6 forward (conv_fwd_x6.hip): the same result as tdvc_conv_fwd at fp32 accuracy on the bf16 matrix pipe, for 3-tap
+ * stride-1 'same' convs with 65..160 input channels and Cout % 32 == 0 (FiLM cond_var.2), prologue none / LeakyReLU, bias, no
+ * other epilogue operand; TDVC_EUNSUPPORTED otherwise (call tdvc_conv_fwd). The weights come pre-split into three exact bf16
+ * pieces: tdvc_conv_x6_weight_planes writes tdvc_conv_x6_weight_planes_bytes() bytes from the fp32 weight [Cout][Cin][3]; redo it
+ * whenever the weight changes (once per optimizer step). */
+size_t tdvc_conv_x6_weight_planes_bytes(int32_t Cout, int32_t Cin, int32_t K);
+int tdvc_conv_x6_weight_planes(const float* w, int32_t Cout, int32_t Cin, int32_t K, void* planes, void* stream);
+int tdvc_conv_fwd_x6(const tdvc_conv_desc* d, const tdvc_conv_fwd_args* a, const void* weight_planes, void* stream);
 int tdvc_conv_dgrad(const tdvc_conv_desc* d, const tdvc_conv_dgrad_args* a, void* stream);
 int tdvc_conv_wgrad(const tdvc_conv_desc* d, const tdvc_conv_wgrad_args* a, void* stream);
 size_t tdvc_conv_wgrad_workspace(const tdvc_conv_desc* d);
@@ -135,7 +143,7 @@ void tdvc_fold_reset(void* stream);
  *   instantiations launched; tdvc_debug_trace_dump copies them ('\n'-separated, NUL-terminated) and returns the size needed. */
 void tdvc_set_force_generic(int on);
 void tdvc_debug_force_tile(int cfg);
-void tdvc_debug_knob(int which, int value); /* tuning knobs for A/B measurements: 0 = XCD-aware block order of the lean conv kernel (1 = on; default 0: measured null on this path); 3 = one block per CU in the fused conditioning backward (diagnostic); 4 = 1: no sample folding of short sequences (T = 16 / 32) in the lean conv kernel; 5 = 1: exact-fp32 MFMA instead of the split-bf16 x6 weight-grad kernel (conv_wgrad_x6.hip) */
+void tdvc_debug_knob(int which, int value); /* tuning knobs for A/B measurements: 0 = XCD-aware block order of the lean conv kernel (1 = on; default 0: measured null on this path); 3 = one block per CU in the fused conditioning backward (diagnostic); 4 = 1: no sample folding of short sequences (T = 16 / 32) in the lean conv kernel; 5 = 1: exact-fp32 MFMA instead of the split-bf16 x6 weight-grad kernel (conv_wgrad_x6.hip); 6 = 1: tdvc_conv_fwd_x6 always answers TDVC_EUNSUPPORTED */
 void tdvc_debug_lds_cap(int bytes);   /* tuning knob: LDS bytes per block the lean kernel's chunk-size choice may use (0 = built-in) */
 void tdvc_debug_trace(int on);
 size_t tdvc_debug_trace_dump(char* buf, size_t cap);

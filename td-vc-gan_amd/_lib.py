@@ -93,6 +93,9 @@ SIGNATURES = {
     'tdvc_conv_dgrad': (_i, [C.POINTER(ConvDesc), C.POINTER(ConvDgradArgs), _vp]),
     'tdvc_conv_wgrad': (_i, [C.POINTER(ConvDesc), C.POINTER(ConvWgradArgs), _vp]),
     'tdvc_conv_wgrad_workspace': (C.c_size_t, [C.POINTER(ConvDesc)]),
+    'tdvc_conv_x6_weight_planes_bytes': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32]),
+    'tdvc_conv_x6_weight_planes': (_i, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
+    'tdvc_conv_fwd_x6': (_i, [C.POINTER(ConvDesc), C.POINTER(ConvFwdArgs), _vp, _vp]),
     'tdvc_film_cond_fwd': (_i, [C.POINTER(FilmCondArgs), _vp]),
     'tdvc_film_cond0_bwd': (_i, [C.POINTER(FilmCond0BwdArgs), _vp]),
     'tdvc_film_cond_bwd': (_i, [C.POINTER(FilmCondBwdArgs), _vp]),
@@ -175,6 +178,9 @@ def lib():
             fn = getattr(l, name)      # AttributeError if the .so does not export a declared symbol
             fn.restype, fn.argtypes = res, args
         _lib = l
+        for kv in filter(None, os.environ.get('TDVC_KNOBS', '').split(',')):      # diagnostic: "5=1,6=1" presets tdvc_debug_knob values
+            k, v = kv.split('=')
+            l.tdvc_debug_knob(int(k), int(v))
     return _lib
 
 

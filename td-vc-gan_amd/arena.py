@@ -153,6 +153,8 @@ class ParamArena:
         else:
             self.nrows = 0
         self.wgrad_enabled = True
+        self.version = 0               # bumped by materialize(): derived copies of the weights (ops._weight_planes_x6) key on it
+        self.x6_planes = {}            # effective-weight address -> (version, bf16 piece planes)
         self.token = torch.zeros(1, dtype=torch.float32, device=self.device, requires_grad=True)
         self._grads_attached = False
         self._finish_queued = False
@@ -201,6 +203,7 @@ class ParamArena:
     # ------------------------------------------------------------------ per-step kernels
     def materialize(self):
         """w = g * v / ||v|| for every weight-normed tensor: one launch."""
+        self.version += 1
         if self.nrows:
             st = torch.cuda.current_stream(self.device).cuda_stream
             L.check(L.lib().tdvc_weight_norm_fwd_t(self.P.data_ptr(), self.W.data_ptr(), self.WT.data_ptr(),

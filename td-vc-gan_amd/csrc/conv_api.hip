@@ -49,7 +49,7 @@ static bool lean_shape_ok(const tdvc_conv_desc* d) {
   return d->kind == TDVC_CONV && d->stride == 1 && d->groups == 1 && d->Tin == d->Tout && ((d->Tin & 3) == 0 || d->Tin <= 80);
 }
 
-static int g_force_generic = 0;   // test-only switch, like the tdvc_debug_* hooks (misc_kernels.hip)
+namespace tdvc { int g_force_generic = 0; }   // test-only switch, like the tdvc_debug_* hooks (misc_kernels.hip)
 extern "C" void tdvc_set_force_generic(int on) { g_force_generic = on; }
 
 static Xf to_xf(const tdvc_xform& x) {

@@ -24,6 +24,7 @@
 namespace tdvc {
 extern int g_trace_on;
 extern int g_force_tile;
+extern int g_force_generic;      // conv_api.hip: tests route every conv to the scalar kernels
 extern int g_lds_cap;
 extern int g_knob[8];   // tuning knobs (tdvc_debug_knob): [0] XCD-aware block order of the lean conv kernel (default off: measured null, profiles/r02_e_xcd_remap_ab.txt)
 void trace_kernel(const void* fn);

@@ -128,12 +128,43 @@ def _check_layout(t):
         raise L.TdvcError('operand must be [B,C,T] with contiguous (C,T) planes')
 
 
+X6_FWD = os.environ.get('TDVC_X6_FWD', '1') == '1'      # split-bf16 x6 forward for FiLM's cond_var.2 (tdvc_conv_fwd_x6); 0 = exact-fp32 MFMA kernel
+X6_FWD_MIN_COUT = 64  # the 2-tile variant (Cout = 32) is slower than the fp32 kernel at T = 16000 (profiles/r03_*_fwd_x6*): not routed
+
+
+def _weight_planes_x6(spec, device):
+    """The three exact bf16 pieces of the layer's effective weight ([piece][Cout][tap][160] bf16). Cached on the arena that owns the
+    weight and refreshed when it has re-materialised (arena.version: once per forward pass that may follow an optimizer step);
+    stand-alone slots (tests, tools) split on every call."""
+    s = spec.slot
+    lib = L.lib()
+    ent = s.arena.x6_planes.get(s.w) if s.arena is not None else None
+    if ent is None or ent[0] != s.arena.version:
+        buf = ent[1] if ent is not None else torch.empty(lib.tdvc_conv_x6_weight_planes_bytes(spec.cout, spec.cin, spec.k), dtype=torch.uint8, device=device)
+        L.check(lib.tdvc_conv_x6_weight_planes(s.w, spec.cout, spec.cin, spec.k, buf.data_ptr(), torch.cuda.current_stream(device).cuda_stream))
+        ent = (s.arena.version if s.arena is not None else None, buf)
+        if s.arena is not None:
+            s.arena.x6_planes[s.w] = ent
+    return ent[1]
+
+
 def conv_fwd_raw(spec: ConvSpec, x, x_xf, post=L.POST_NONE, res=None, add=None, out_scale=1.0, out=None, w_ptr=None, b_ptr=None,
                  bias3=None, sign_bits=None):
     B, _, tin = x.shape
     d = spec.desc(B, tin)
     y = out if out is not None else torch.empty((B, spec.cout, d.Tout), dtype=torch.float32, device=x.device)
     _check_layout(x); _check_layout(y)
+    if (X6_FWD and spec.k == 3 and spec.kind == L.CONV and spec.stride == 1 and spec.dil == 1 and spec.pad == 1 and spec.groups == 1 and not spec.reflect
+            and spec.w_cin == 0 and 64 < spec.cin <= 160 and spec.cout % 32 == 0 and spec.cout >= X6_FWD_MIN_COUT and tin >= 128 and tin % 4 == 0 and post == L.POST_NONE and res is None
+            and add is None and bias3 is None and sign_bits is None and w_ptr is None and x_xf.kind in (L.XF_NONE, L.XF_LRELU) and out_scale == 1.0):
+        a = L.ConvFwdArgs(x.data_ptr(), _bs(x), x_xf, spec.slot.w, (b_ptr if b_ptr is not None else spec.slot.b) or None, None, 0, post, SLOPE, 1.0,
+                          None, 0, y.data_ptr(), _bs(y), None, None, 0)
+        rc = L.lib().tdvc_conv_fwd_x6(C.byref(d), C.byref(a), _weight_planes_x6(spec, x.device).data_ptr(), _stream(x))
+        if rc != L.EUNSUPPORTED:
+            L.check(rc)
+            if RECORDER is not None:
+                RECORDER.append(('fwd_x6', _spec_key(spec), B, tin, x_xf.kind, bool((b_ptr if b_ptr is not None else spec.slot.b))))
+            return y
     if RECORDER is not None:
         RECORDER.append(('fwd', _spec_key(spec), B, tin, x_xf.kind, post, res is not None, add is not None,
                          bool((b_ptr if b_ptr is not None else spec.slot.b)), bias3 is not None, sign_bits is not None))

@@ -254,6 +254,71 @@ def test_split_bf16_x6_weight_grad(case, B, dev):
     assert errs['dw'] <= 4 * errs1['dw'] + 1e-7, (errs['dw'], errs1['dw'])      # not worse than the fp32 kernel's own rounding
 
 
+# conv_fwd_x6.hip: the same arithmetic for the forward of a 3-tap conv with 64 < Cin <= 160 (cond_var.2): x split on the fly while it is
+# transposed into LDS, the weight pieces cached once per optimizer step (ops._weight_planes_x6). Ragged T (not a multiple of the 128-step
+# tile, down to the minimum 128), Cin at both ends of the window (65, 160), Cout 32-multiples handled by the 2- and the 4-tile variant,
+# with / without LeakyReLU on load; knob 6 = the exact-fp32 MFMA kernel on the same case.
+X6_FWD_CASES = [(('x6f_136_32_T500', 136, 32, 3, 1, 1, 1, 1, False, False, 500, 1, 0), 3),
+                (('x6f_65_64_T132', 65, 64, 3, 1, 1, 1, 1, False, False, 132, 0, 0), 2),
+                (('x6f_160_96_T128', 160, 96, 3, 1, 1, 1, 1, False, False, 128, 1, 0), 2),
+                (('x6f_136_128_T1000', 136, 128, 3, 1, 1, 1, 1, False, False, 1000, 1, 0), 3),
+                (('x6f_cond2_136_64_T8000', 136, 64, 3, 1, 1, 1, 1, False, False, 8000, 1, 0), 32),
+                (('x6f_cond2_136_256_T500', 136, 256, 3, 1, 1, 1, 1, False, False, 500, 1, 0), 32)]
+
+
+@pytest.mark.parametrize('case,B', X6_FWD_CASES, ids=[c[0][0] for c in X6_FWD_CASES])
+def test_split_bf16_x6_forward(case, B, dev):
+    P = importlib.import_module('td-vc-gan_amd')
+    lib = P._lib.lib()
+    old = P.ops.X6_FWD_MIN_COUT
+    P.ops.X6_FWD_MIN_COUT = 32                         # also the variants the step does not route (kept correct, selectable)
+    try:
+        with traced() as tr:
+            errs = OPS.conv_case_errors(case, dev, 0, B=B)
+        assert max(errs.values()) < TOL, (errs, sorted(tr.names))
+        assert any(n.startswith('conv_fwd_x6_kernel') for n in tr.names), sorted(tr.names)
+        lib.tdvc_debug_knob(6, 1)                      # exact-fp32 MFMA path on the same case
+        try:
+            with traced() as tr1:
+                errs1 = OPS.conv_case_errors(case, dev, 0, B=B)
+        finally:
+            lib.tdvc_debug_knob(6, 0)
+    finally:
+        P.ops.X6_FWD_MIN_COUT = old
+    assert max(errs1.values()) < TOL and not any(n.startswith('conv_fwd_x6_kernel') for n in tr1.names), (errs1, sorted(tr1.names))
+    assert errs['y'] <= 4 * errs1['y'] + 1e-7, (errs['y'], errs1['y'])
+
+
+def test_split_bf16_x6_forward_weight_cache(dev):
+    """The cached bf16 weight pieces follow the arena's weights: they key on arena.version, which every materialize() bumps. A stale
+    cache would reproduce the old output exactly; here the layer's weight is scaled by 1.5 in place between two forwards."""
+    from common import build_models
+    P = importlib.import_module('td-vc-gan_amd')
+    ops, L = P.ops, P._lib
+    G, _ = build_models(dev)
+    ar = G.ensure_arena(dev)
+    name, mod = next((n, m) for n, m in G.named_modules() if n.endswith('cond_var.2') and m.spec.cout >= ops.X6_FWD_MIN_COUT and m.spec.cout % 32 == 0)
+    spec = mod.spec
+    torch.manual_seed(3)
+    x = torch.randn(2, spec.cin, 512, device=dev)
+    with traced() as tr:
+        y1 = ops.conv_fwd_raw(spec, x, ops._xf(L.XF_NONE)).clone()
+    assert any(n.startswith('conv_fwd_x6_kernel') for n in tr.names), sorted(tr.names)
+    wkey = name + ('.weight_g' if name + '.weight_g' in ar.params else '.weight')
+    bias = ar.params[name + '.bias'].detach().view(1, -1, 1)
+    with torch.no_grad():
+        ar.params[wkey].mul_(1.5)
+    try:
+        ar.materialize()
+        y2 = ops.conv_fwd_raw(spec, x, ops._xf(L.XF_NONE))
+        ref = 1.5 * (y1 - bias) + bias
+        assert float((y2 - ref).norm() / ref.norm()) < 1e-6, float((y2 - ref).norm() / ref.norm())
+    finally:
+        with torch.no_grad():
+            ar.params[wkey].div_(1.5)
+        ar.materialize()
+
+
 # ------------------------------------------------------------------------------------------------ sign-bit masks
 # tdvc_conv_fwd_args.sign_bits / tdvc_conv_dgrad_args.x_sign_bits: the forward epilogue packs (y > 0) into one bit per element,
 # the LeakyReLU-mask epilogue of the next layer's input-grad reads those words instead of the fp32 tensor (FiLM conditioning:
