@@ -3,13 +3,16 @@
 // exact bf16 pieces per operand, six piece products on v_mfma_f32_16x16x32_bf16, fp32 accumulation).
 //     y[co][t] = bias[co] + sum_{ci,j} W[co][ci][j] * x'[ci][t + j - 1],      x' = LeakyReLU(x) (or x)
 // K of the product is (tap, input channel): a lane's 8 consecutive k values are 8 consecutive CHANNELS at one time step, so the
-// activation tile is held TRANSPOSED in LDS ([time][channel], channel fastest; the tap shift is a row shift -> every fragment
-// read is an aligned ds_read_b128). The transposition happens in registers on the way in: a staging thread loads 8 channel
-// rows x 4 consecutive steps (8 coalesced float4 loads), splits the 32 values and writes, per step and piece, the 8 channels
-// as one 16-byte LDS store. The weights arrive pre-split ([piece][co][tap][160 channels] bf16, tdvc_conv_x6_weight_planes:
-// once per optimizer step) and are copied as they are.
+// activation tile is held TRANSPOSED in LDS ([time][channel], channel fastest). The transposition happens in registers on the
+// way in: every thread loads 4 channel rows x 4 consecutive steps (coalesced float4 loads), splits the 16 values and writes,
+// per step and piece, its 4 channels as one 8-byte LDS store. The weights arrive pre-split and already in the order of the
+// LDS image (tdvc_conv_x6_weight_planes: once per optimizer step), so a chunk is copied with linear 16-byte loads.
+// Roles in the MFMA: A = weights (rows = output channels), B = activations (columns = time). The columns of sub-tile n are
+// the steps 4l + n (l = 0..15), so that a lane's four accumulators of one output channel are four CONSECUTIVE steps and a
+// store instruction covers 4 channel rows x 256 B (16 rows x 64 B with the natural column order). For conflict-free fragment
+// reads under that permutation the activation tile is kept as four phase planes (step mod 4).
 // Block = 128 steps x (32 | 64) output channels, reduction in chunks of 32 input channels (x all 3 taps); wave w owns steps
-// 32w .. 32w + 31 (two 16-row tiles) x all output-channel tiles. Loads of chunk c + 1 are in flight during the MFMAs of chunk c.
+// 64 (w & 1) .. + 63 x half of the output-channel tiles. Loads of chunk c + 1 are in flight during the MFMAs of chunk c.
 #include "conv_common.h"
 #include "api_util.h"
 
@@ -19,11 +22,12 @@ namespace tdvc {
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 struct FwdX6P {
   const float* x; long x_bs;            // [B][Cin][T]
-  const unsigned short* wp;             // [3 pieces][Cout][3 taps][FX_CP] bf16
+  const unsigned short* wp;             // [Cout / MT][5 chunks][MT / 32 records][3 pieces][32 co][3 taps][32 ci] bf16, MT = 64 | 32 (x6_mt)
   const float* bias;                    // [Cout] or null
   float* y; long y_bs;
   int T, Cin, Cout;
@@ -33,61 +37,88 @@ struct FwdX6P {
 constexpr int FX_NT = 128;              // steps per block
 constexpr int FX_CP = 160;              // padded channel count of the weight planes (5 chunks of 32)
 constexpr int FX_RS = 40;               // bf16 row stride of both LDS images: 80 B -> 16 rows start on 16 distinct 4-bank groups
-constexpr int FX_XROWS = FX_NT + 8;     // window [n0 - 4, n0 + 132): row i <-> position n0 - 4 + i
-constexpr int FX_XPL = FX_XROWS * FX_RS;
-constexpr int FX_NV = FX_XROWS / 4;     // 34 float4 columns per channel row
+constexpr int FX_PR = 34;               // rows of one phase plane: window index s = position - (n0 - 4) = 4 row + phase, s in [3, 132]
+constexpr int FX_XPL = 4 * FX_PR * FX_RS;   // one piece of the activation tile: [phase][row][FX_RS]
+constexpr int FX_WREC = 3 * 32 * 3 * 4;     // 16-byte vectors of one weight record (32 output channels x one chunk): [piece][co][tap][4]
 
-__device__ __forceinline__ void split1(const float f, unsigned& h, unsigned& m, unsigned& l) {     // exact: f = h + m + l (upper halves)
+// exact: f = h + m + l, each piece the UPPER half of its word (l's lower half is zero by construction: 24 significant bits in all;
+// it is left unmasked and dropped by the pack)
+__device__ __forceinline__ void split1(const float f, unsigned& h, unsigned& m, unsigned& l) {
   h = __builtin_bit_cast(unsigned, f) & 0xffff0000u;
   const float r1 = f - __builtin_bit_cast(float, h);
   m = __builtin_bit_cast(unsigned, r1) & 0xffff0000u;
   const float r2 = r1 - __builtin_bit_cast(float, m);
-  l = __builtin_bit_cast(unsigned, r2) & 0xffff0000u;
+  l = __builtin_bit_cast(unsigned, r2);
+}
+__device__ __forceinline__ unsigned pack_hi(unsigned a, unsigned b) {      // {upper half of a, upper half of b}: a in the low 16 bits
+  return __builtin_amdgcn_perm(b, a, 0x07060302u);
 }
 
 template <int CO_TILES>
 __global__ __launch_bounds__(256, 2) void conv_fwd_x6_kernel(const FwdX6P p) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
   constexpr int MT = 16 * CO_TILES;
-  constexpr int WPL = MT * 3 * FX_RS;                 // elements of one weight piece: [co][tap][FX_RS]
-  constexpr int WNV = 3 * MT * 3 * 4;                 // 16-byte vectors of a weight chunk: (piece, co, tap) x 4
+  constexpr int CB = MT / 32;                         // weight records per chunk
+  constexpr int CT2 = CO_TILES / 2;                   // output-channel tiles of one wave
+  constexpr int WPL = MT * 3 * FX_RS;                 // elements of one weight piece in LDS: [co][tap][FX_RS]
+  constexpr int WNV = CB * FX_WREC;                   // 16-byte vectors of a weight chunk
   constexpr int WPT = (WNV + 255) / 256;
-  unsigned short* xt = smem16;                        // [3 pieces][FX_XROWS][FX_RS]
+  unsigned short* xt = smem16;                        // [3 pieces][4 phases][FX_PR][FX_RS]
   unsigned short* ws = smem16 + 3 * FX_XPL;           // [3 pieces][MT][3][FX_RS]
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wt = wave & 1, wc = wave >> 1;
   const int ln = lane & 15, g = lane >> 4;
   const int T = p.T, n0 = blockIdx.x * FX_NT, r0 = blockIdx.y * MT, b = blockIdx.z;
-  const int nchunk = (p.Cin + 31) / 32;
+  const int nchunk = (p.Cin + 31) >> 5;
 
-  // staging roles. x: thread (channel group cg of 8, float4 column v) for tid < 4 * 34; weights: vector e = tid + i * 256
-  const int cg = tid / FX_NV, xv = tid - cg * FX_NV;
-  const bool xact = tid < 4 * FX_NV;
-  const int q = n0 - 4 + 4 * xv;
-  const bool xin = xact && q >= 0 && q < T;            // T % 4 == 0: a float4 lies wholly inside or outside
-  const srd_t xrs = make_srd(p.x + (long)b * p.x_bs, p.Cin * T * 4);         // channels >= Cin read as zero
-  const srd_t wrs = make_srd(reinterpret_cast<const float*>(p.wp), 3 * p.Cout * 3 * FX_CP * 2);
+  // staging roles. x: thread (channel group c4 of 4, float4 column xv) -> steps n0 + 4 xv .. + 3; threads 0..63 also carry one halo
+  // element each (channel tid & 31 at position n0 - 1 | n0 + 128); weights: vector e = tid + 256 i of the chunk's records
+  const int c4 = tid >> 5, xv = tid & 31;
+  const bool xin = n0 + 4 * xv < T;                    // T % 4 == 0: a float4 lies wholly inside or outside
+  const int hpos = (tid & 32) ? n0 + FX_NT : n0 - 1;
+  const bool hin = tid < 64 && hpos >= 0 && hpos < T;
+  const srd_t xrs = make_srd(p.x + (long)b * p.x_bs, p.Cin * T * 4);         // (channels >= Cin are masked per load: the scalar chunk offset may not take part in the range check)
+  const srd_t wrs = make_srd(reinterpret_cast<const float*>(p.wp), (p.Cout >> 5) * 5 * FX_WREC * 16);
 
-  f32x4 acc[2][CO_TILES];
+  f32x4 acc[CT2][4];
 #pragma unroll
-  for (int tt = 0; tt < 2; ++tt)
+  for (int ct = 0; ct < CT2; ++ct)
 #pragma unroll
-    for (int ct = 0; ct < CO_TILES; ++ct) acc[tt][ct] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int n = 0; n < 4; ++n) acc[ct][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  f32x4 xr[8];
+  float bias[CT2][4];                                 // loaded up front: a dependent global load in the epilogue costs its full latency
+#pragma unroll
+  for (int ct = 0; ct < CT2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = r0 + 16 * (wc * CT2 + ct) + 4 * g + r;
+      bias[ct][r] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+    }
+
+  const int xo = (4 * c4 * T + n0 + 4 * xv) * 4, ho = ((tid & 31) * T + hpos) * 4;      // byte offsets inside a chunk's 32 channel rows
+  int wl[WPT];                                        // LDS element offset of the thread's i-th weight vector (chunk invariant)
+#pragma unroll
+  for (int i = 0; i < WPT; ++i) {
+    const int e = tid + i * 256;
+    const int cb = e / FX_WREC, er = e - cb * FX_WREC;
+    const int row = er >> 2, pc = row / 96, rr = row - pc * 96;            // rr = co * 3 + tap
+    wl[i] = pc * WPL + (cb * 96 + rr) * FX_RS + 8 * (er & 3);
+  }
+
+  f32x4 xr[4];
+  float hr;
   u32x4 wr[WPT];
   auto issue = [&](int c) {
     const int c0 = c * 32;
 #pragma unroll
-    for (int e = 0; e < 8; ++e) xr[e] = buf_load4(xrs, xin ? ((c0 + 8 * cg + e) * T + q) * 4 : 0x7f000000);
+    for (int e = 0; e < 4; ++e)
+      xr[e] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(xrs, (xin && c0 + 4 * c4 + e < p.Cin) ? xo + e * T * 4 : 0x7f000000, c0 * T * 4, 0));
+    hr = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(xrs, (hin && c0 + (tid & 31) < p.Cin) ? ho : 0x7f000000, c0 * T * 4, 0));
 #pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-      const int e = tid + i * 256;                    // (piece, co, tap, 16-byte quarter)
-      const int row = e >> 2, qu = e & 3;             // row = (piece * MT + co) * 3 + tap
-      const int pc = row / (MT * 3), rem = row - pc * MT * 3;
-      const int co = rem / 3, j = rem - co * 3;
-      wr[i] = __builtin_bit_cast(u32x4, buf_load4(wrs, e < WNV ? (((pc * p.Cout + r0 + co) * 3 + j) * FX_CP + c0 + 8 * qu) * 2 : 0x7f000000));
-    }
+    for (int i = 0; i < WPT; ++i)                     // the block's chunk is one linear run of WNV vectors
+      wr[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (tid + i * 256 < WNV) ? (tid + i * 256) * 16 : 0x7f000000,
+                                                                              (blockIdx.y * 5 + c) * (WNV * 16), 0));
   };
   PROF_DECL
   issue(0);
@@ -98,95 +129,104 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6_kernel(const FwdX6P p) {
     PROF(1)
     PROF_WAITV()
     PROF(2)
-    if (xact) {
-      // 8 channels x 4 steps in registers -> per step and piece one 16-byte store of the 8 channels
-      unsigned hh[4][8], mm[4][8], ll[4][8];
+    // 4 channels x 4 steps in registers -> per step and piece one 8-byte store of the 4 channels. Step n0 + 4 xv + k is window index
+    // 4 (xv + 1) + k: phase k, row xv + 1
 #pragma unroll
-      for (int e = 0; e < 8; ++e)
+    for (int k = 0; k < 4; ++k) {
+      unsigned hh[4], mm[4], ll[4];
 #pragma unroll
-        for (int k = 0; k < 4; ++k) {
-          const float f0 = xr[e][k];
-          const float f = fmaxf(f0, f0 * p.slope);    // slope in (0, 1]: LeakyReLU; 1: identity
-          split1(f, hh[k][e], mm[k][e], ll[k][e]);
-        }
-#pragma unroll
-      for (int k = 0; k < 4; ++k) {
-        const int off = (4 * xv + k) * FX_RS + 8 * cg;
-        *reinterpret_cast<u32x4*>(xt + 0 * FX_XPL + off) = (u32x4){(hh[k][0] >> 16) | hh[k][1], (hh[k][2] >> 16) | hh[k][3], (hh[k][4] >> 16) | hh[k][5], (hh[k][6] >> 16) | hh[k][7]};
-        *reinterpret_cast<u32x4*>(xt + 1 * FX_XPL + off) = (u32x4){(mm[k][0] >> 16) | mm[k][1], (mm[k][2] >> 16) | mm[k][3], (mm[k][4] >> 16) | mm[k][5], (mm[k][6] >> 16) | mm[k][7]};
-        *reinterpret_cast<u32x4*>(xt + 2 * FX_XPL + off) = (u32x4){(ll[k][0] >> 16) | ll[k][1], (ll[k][2] >> 16) | ll[k][3], (ll[k][4] >> 16) | ll[k][5], (ll[k][6] >> 16) | ll[k][7]};
+      for (int e = 0; e < 4; ++e) {
+        const float f0 = xr[e][k];
+        const float f = fmaxf(f0, f0 * p.slope);      // slope in (0, 1]: LeakyReLU; 1: identity
+        split1(f, hh[e], mm[e], ll[e]);
       }
+      const int off = (k * FX_PR + xv + 1) * FX_RS + 4 * c4;
+      *reinterpret_cast<u32x2*>(xt + 0 * FX_XPL + off) = (u32x2){pack_hi(hh[0], hh[1]), pack_hi(hh[2], hh[3])};
+      *reinterpret_cast<u32x2*>(xt + 1 * FX_XPL + off) = (u32x2){pack_hi(mm[0], mm[1]), pack_hi(mm[2], mm[3])};
+      *reinterpret_cast<u32x2*>(xt + 2 * FX_XPL + off) = (u32x2){pack_hi(ll[0], ll[1]), pack_hi(ll[2], ll[3])};
+    }
+    if (tid < 64) {                                   // halo: window index 3 (phase 3, row 0) | 132 (phase 0, row 33)
+      unsigned h, m, l;
+      split1(fmaxf(hr, hr * p.slope), h, m, l);
+      const int off = ((tid & 32) ? (FX_PR - 1) : 3 * FX_PR) * FX_RS + (tid & 31);
+      xt[0 * FX_XPL + off] = (unsigned short)(h >> 16);
+      xt[1 * FX_XPL + off] = (unsigned short)(m >> 16);
+      xt[2 * FX_XPL + off] = (unsigned short)(l >> 16);
     }
 #pragma unroll
-    for (int i = 0; i < WPT; ++i) {
-      const int e = tid + i * 256;
-      if (e < WNV) *reinterpret_cast<u32x4*>(ws + (e >> 2) * FX_RS + 8 * (e & 3)) = wr[i];
-    }
+    for (int i = 0; i < WPT; ++i)
+      if (tid + i * 256 < WNV) *reinterpret_cast<u32x4*>(ws + wl[i]) = wr[i];
     PROF(3)
     __syncthreads();
     PROF(4)
     if (c + 1 < nchunk) issue(c + 1);
     PROF(5)
 
-    // ---- one k-block (32 channels) per tap: A = x'^T rows (steps), B = weights (output channels); lane (ln, g): k = 8g .. 8g + 7
+    // ---- one k-block (32 channels) per tap; lane (ln, g): k = 8g .. 8g + 7. Column ln of sub-tile n is step 64 wt + 4 ln + n, which
+    // at tap j reads window index 64 wt + 4 ln + (n + j + 3): phase (n + j + 3) & 3, row 16 wt + ln + ((n + j + 3) >> 2)
 #pragma unroll
     for (int j = 0; j < 3; ++j) {
-      bf16x8 af[2][3];
+      bf16x8 af[CT2][3];
 #pragma unroll
-      for (int tt = 0; tt < 2; ++tt)
+      for (int ct = 0; ct < CT2; ++ct)
 #pragma unroll
-        for (int pc = 0; pc < 3; ++pc)                 // step t = n0 + 32w + 16tt + ln needs position t + j - 1 = window row 32w + 16tt + ln + j + 3
-          af[tt][pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xt + pc * FX_XPL + (32 * wave + 16 * tt + ln + j + 3) * FX_RS + 8 * g));
+        for (int pc = 0; pc < 3; ++pc)
+          af[ct][pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ws + pc * WPL + ((16 * (wc * CT2 + ct) + ln) * 3 + j) * FX_RS + 8 * g));
 #pragma unroll
-      for (int ct = 0; ct < CO_TILES; ++ct) {
+      for (int n = 0; n < 4; ++n) {
+        const int m = n + j + 3;
         bf16x8 bf[3];
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc)
-          bf[pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ws + pc * WPL + ((16 * ct + ln) * 3 + j) * FX_RS + 8 * g));
+          bf[pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xt + pc * FX_XPL + ((m & 3) * FX_PR + 16 * wt + ln + (m >> 2)) * FX_RS + 8 * g));
 #pragma unroll
-        for (int tt = 0; tt < 2; ++tt) {              // smallest products first
-          f32x4 cc = acc[tt][ct];
-          cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tt][2], bf[0], cc, 0, 0, 0);
-          cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tt][0], bf[2], cc, 0, 0, 0);
-          cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tt][1], bf[1], cc, 0, 0, 0);
-          cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tt][1], bf[0], cc, 0, 0, 0);
-          cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tt][0], bf[1], cc, 0, 0, 0);
-          cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[tt][0], bf[0], cc, 0, 0, 0);
-          acc[tt][ct] = cc;
+        for (int ct = 0; ct < CT2; ++ct) {            // smallest products first
+          f32x4 cc = acc[ct][n];
+          cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ct][2], bf[0], cc, 0, 0, 0);
+          cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ct][0], bf[2], cc, 0, 0, 0);
+          cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ct][1], bf[1], cc, 0, 0, 0);
+          cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ct][1], bf[0], cc, 0, 0, 0);
+          cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ct][0], bf[1], cc, 0, 0, 0);
+          cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ct][0], bf[0], cc, 0, 0, 0);
+          acc[ct][n] = cc;
         }
       }
     }
     PROF(6)
   }
 
-  // ---- epilogue: D[t = 4g + r][co = ln] -> 4 consecutive steps of one output channel per lane
+  // ---- epilogue: D[co = 4g + r][column ln] of sub-tiles n = 0..3 -> 4 consecutive steps of one output channel per lane and register
+  const int t0 = n0 + 64 * wt + 4 * ln;
 #pragma unroll
-  for (int ct = 0; ct < CO_TILES; ++ct) {
-    const int co = r0 + 16 * ct + ln;
-    const float bias = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+  for (int ct = 0; ct < CT2; ++ct)
 #pragma unroll
-    for (int tt = 0; tt < 2; ++tt) {
-      const int t0 = n0 + 32 * wave + 16 * tt + 4 * g;
+    for (int r = 0; r < 4; ++r) {
+      const int co = r0 + 16 * (wc * CT2 + ct) + 4 * g + r;
       if (co < p.Cout && t0 < T) {
-        f32x4 v = acc[tt][ct];
-#pragma unroll
-        for (int k = 0; k < 4; ++k) v[k] += bias;
-        *reinterpret_cast<f32x4*>(p.y + (long)b * p.y_bs + (long)co * T + t0) = v;
+        const float bs = bias[ct][r];
+        const float v0 = acc[ct][0][r], v1 = acc[ct][1][r], v2 = acc[ct][2][r], v3 = acc[ct][3][r];
+        *reinterpret_cast<f32x4*>(p.y + (long)b * p.y_bs + (long)co * T + t0) = (f32x4){v0 + bs, v1 + bs, v2 + bs, v3 + bs};
       }
     }
-  }
   PROF(8)
   PROF_END
 }
 
-// fp32 weights [Cout][Cin][3] -> [piece][Cout][tap][FX_CP] bf16 pieces (zero for channels >= Cin)
+__host__ __device__ __forceinline__ int x6_mt(int Cout) { return (Cout % 64 == 0) ? 64 : 32; }      // output channels per block
+
+// fp32 weights [Cout][Cin][3] -> [Cout / MT][5 chunks][MT / 32 records][piece][32 co][tap][32 ci] bf16 pieces (zero for channels >= Cin):
+// the 32-channel chunk of one block's MT output channels is one linear run, in the order of the kernel's LDS image
 __global__ __launch_bounds__(256) void conv_x6_weight_planes_kernel(const float* w, int Cout, int Cin, unsigned short* planes) {
-  const int n = Cout * 3 * FX_CP;
+  const int n = Cout * 3 * FX_CP;                     // elements of one piece over all records
+  const int cbn = x6_mt(Cout) >> 5;                   // records per (block, chunk)
   for (int i = blockIdx.x * 256 + threadIdx.x; i < n; i += gridDim.x * 256) {
-    const int ci = i % FX_CP, rest = i / FX_CP, j = rest % 3, co = rest / 3;
+    const int ci32 = i & 31, j = (i >> 5) % 3, rest = (i >> 5) / 3;         // rest = ((blk * 5 + chunk) * cbn + cb) * 32 + co32
+    const int co32 = rest & 31, rec = rest >> 5, cb = rec % cbn, chunk = (rec / cbn) % 5, blk = rec / (cbn * 5);
+    const int co = (blk * cbn + cb) * 32 + co32, ci = chunk * 32 + ci32;
     unsigned h = 0, m = 0, l = 0;
     if (ci < Cin) split1(w[((long)co * Cin + ci) * 3 + j], h, m, l);
-    planes[i] = (unsigned short)(h >> 16); planes[n + i] = (unsigned short)(m >> 16); planes[2 * n + i] = (unsigned short)(l >> 16);
+    unsigned short* o = planes + (long)rec * (3 * 32 * 3 * 32) + (co32 * 3 + j) * 32 + ci32;
+    o[0] = (unsigned short)(h >> 16); o[32 * 3 * 32] = (unsigned short)(m >> 16); o[2 * 32 * 3 * 32] = (unsigned short)(l >> 16);
   }
 }
 
@@ -222,7 +262,7 @@ extern "C" int tdvc_conv_fwd_x6(const tdvc_conv_desc* d, const tdvc_conv_fwd_arg
   p.T = d->Tin; p.Cin = d->Cin; p.Cout = d->Cout; p.slope = a->x_xf.kind == TDVC_XF_LRELU ? a->x_xf.slope : 1.f;
   hipStream_t st = (hipStream_t)stream;
   const int nt = (d->Tin + FX_NT - 1) / FX_NT;
-  if (d->Cout % 64 == 0) {
+  if (x6_mt(d->Cout) == 64) {
     auto k = conv_fwd_x6_kernel<4>;
     TDVC_BIG_LDS_ONCE(k); TDVC_TRACE(k);
     hipLaunchKernelGGL(k, dim3(nt, d->Cout / 64, d->B), dim3(256), (size_t)(3 * FX_XPL + 3 * 64 * 3 * FX_RS) * 2, st, p);

@@ -129,7 +129,7 @@ def _check_layout(t):
 
 
 X6_FWD = os.environ.get('TDVC_X6_FWD', '1') == '1'      # split-bf16 x6 forward for FiLM's cond_var.2 (tdvc_conv_fwd_x6); 0 = exact-fp32 MFMA kernel
-X6_FWD_MIN_COUT = 64  # the 2-tile variant (Cout = 32) is slower than the fp32 kernel at T = 16000 (profiles/r03_*_fwd_x6*): not routed
+X6_FWD_MIN_COUT = 32  # smallest Cout routed to the split-bf16 forward (profiles/r03_d_fwd_x6_vs_fp32.txt: 1.19x the fp32 kernel at Cout = 32, 1.5-1.7x above)
 
 
 def _weight_planes_x6(spec, device):

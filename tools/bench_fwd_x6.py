@@ -3,7 +3,7 @@ shape, time at the step's launch shapes on rotating operand sets (diagnostic).""
 import importlib, os, sys, torch
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
 pkg = importlib.import_module('td-vc-gan_amd'); ops, L, arena = pkg.ops, pkg._lib, pkg.arena
-lib = L.lib(); dev = torch.device('cuda:0')
+lib = L.lib(); dev = torch.device('cuda:0'); ops.X6_FWD_MIN_COUT = 32
 def make(C2, T, B, nset=1, cin=136):
     spec = ops.ConvSpec(cin, C2, 3, pad=1)
     w = torch.randn(C2, cin, 3, device=dev) / (cin * 3) ** 0.5; b = torch.randn(C2, device=dev) * 0.1

@@ -5,7 +5,7 @@ pkg = importlib.import_module('td-vc-gan_amd'); ops, arena, L = pkg.ops, pkg.are
 L.LIB_PATH = os.path.join(os.path.dirname(L.LIB_PATH), 'libtdvc_hip_prof.so')
 L.SIGNATURES['tdvc_debug_fwdx6_prof'] = (C.c_int, [C.c_void_p])
 NAMES = ['issue0', 'bar_top', 'wait loads', 'split+store', 'bar_staged', 'issue', 'mfma', 'realtime', 'epilogue', '-']
-dev = torch.device('cuda:0'); lib = L.lib()
+dev = torch.device('cuda:0'); lib = L.lib(); ops.X6_FWD_MIN_COUT = 32
 buf = torch.zeros(10 * 8192, dtype=torch.int64, device=dev)
 for C2, T in ((32, 16000), (64, 8000), (128, 4000)):
     B = 32
