@@ -43,6 +43,7 @@ def parse_args():
                          "init), 'frame' = the one-conv synth.FrameFeatureExtractor of the parity tests")
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-table', action='store_true')
+    ap.add_argument('--exact-fp32', action='store_true', help='exact-fp32 MFMA kernels everywhere (debug knobs 5, 6): no split-bf16 x6 kernels')
     ap.add_argument('--no-graph', action='store_true', help='run eagerly instead of replaying a captured hipGraph')
     ap.add_argument('--force-dp', action='store_true', help='exercise the data-parallel code path (RCCL group, eager launches, '
                                                             'segment-pipelined gradient all-reduce) even with one rank')
@@ -137,6 +138,8 @@ def kernel_table(pkg, dev, classes, step_ms, iters=20, manifest=None, only_ops=N
     lib = L.lib()
     rows = []
     keep = []
+    if manifest is not None:      # closes the segment of everything launched before the table (the recorded iteration)
+        L.check(lib.tdvc_debug_marker(torch.cuda.current_stream(dev).cuda_stream))
 
     def traced(call):
         lib.tdvc_debug_trace(1)
@@ -151,7 +154,11 @@ def kernel_table(pkg, dev, classes, step_ms, iters=20, manifest=None, only_ops=N
             return None
         name = traced(calls[0])
         ms = time_launches(torch, calls, iters)
-        if manifest is not None:      # tools/microbench_kernels.py: lets the PMC summary map dispatches back to this entry
+        if manifest is not None:      # tools/microbench_kernels.py: lets the PMC summary map dispatches back to this entry.
+            # Deferred weight-grad folds are flushed into the entry, then an empty marker dispatch closes it (the number of fold
+            # launches per call is not fixed, so the summary splits the trace at the markers instead of counting dispatches)
+            ops.fold_flush(dev)
+            L.check(lib.tdvc_debug_marker(torch.cuda.current_stream(dev).cuda_stream))
             manifest.append(dict(op=label, kernels=name.split(' + '), calls=1 + len(calls) + 2 + iters))
         if bound is None:
             bound = 'hbm' if flops / max(alg_bytes, 1.0) < RIDGE_F_PER_B else 'mfma'
@@ -442,6 +449,11 @@ def pmc_traffic(op):
         return None
 
 
+DTYPE_EXACT = 'f32'
+DTYPE_DEFAULT = ('f32 (fp32 storage and accumulation everywhere; FiLM cond_var.2 forward and weight-grad as split-bf16 x6 products -- three exact bf16 '
+                 'pieces per operand, six piece products on the bf16 MFMA, fp32 accumulate: fp32-level accuracy; every other kernel exact-fp32 MFMA)')
+
+
 def main():
     args = parse_args()
     spawn_ranks_if_needed(args)
@@ -466,6 +478,8 @@ def main():
             dist.init_process_group('nccl', device_id=dev)
 
     pkg = importlib.import_module('td-vc-gan_amd')
+    if args.exact_fp32:
+        pkg._lib.lib().tdvc_debug_knob(5, 1); pkg._lib.lib().tdvc_debug_knob(6, 1)
     from common import build_models, build_ssl_models, to_dev
     import warnings
     hp = pkg.hparams.HParam(os.path.join(ROOT, 'config', f'{args.config}.yaml'))
@@ -556,6 +570,26 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt)
     g_loss = float(log['G_loss'])
+    # the same K steps on the exact-fp32 kernels (split-bf16 x6 kernels off), reported beside the headline number
+    fp32_ms = None
+    if rank == 0 and world == 1 and not dp and not args.exact_fp32 and use_graph:
+        lib = pkg._lib.lib()
+        lib.tdvc_debug_knob(5, 1); lib.tdvc_debug_knob(6, 1)
+        try:
+            step32 = ts.capture(bt, ix, iy, warmup=1)
+            for _ in range(2):
+                step32()
+            torch.cuda.synchronize()
+            t1 = time.perf_counter()
+            for _ in range(args.steps):
+                step32()
+            torch.cuda.synchronize()
+            fp32_ms = (time.perf_counter() - t1) / args.steps * 1e3
+        except Exception as e:      # noqa: BLE001
+            print(f'[bench] exact-fp32 comparison run failed ({type(e).__name__}: {e})', file=sys.stderr, flush=True)
+            lib.tdvc_fold_reset(torch.cuda.current_stream(dev).cuda_stream)
+        finally:
+            lib.tdvc_debug_knob(5, 0); lib.tdvc_debug_knob(6, 0)
     if rank == 0:
         print(f'[bench] timed region: {dt / args.steps * 1e3:.2f} ms/step (median of the per-step event timings {ms_median:.2f})', file=sys.stderr, flush=True)
     if not (g_loss == g_loss):
@@ -567,7 +601,7 @@ def main():
         stage = 'stage-1' if 'stage1' in args.config else args.config
         out = dict(metric=f'audio-seconds/sec (G+D train step, {stage})', value=value, unit='audio-seconds/sec', n_gpus=world,
                    steps=args.steps, warmup=args.warmup, ms_per_step=step_ms, higher_is_better=True,
-                   scaling='weak', vs_baseline=None, dtype='f32', data='synthetic',
+                   scaling='weak', vs_baseline=None, dtype=DTYPE_EXACT if args.exact_fp32 else DTYPE_DEFAULT, data='synthetic',
                    config=dict(workload=f'config/{args.config}.yaml full D+G iteration, {B} x {args.seconds:g} s @16 kHz per GPU, NUM_SPK=16, '
                                         'F0 (CREPE) loss term excluded' + ((', frozen SSL extractor = ' + ('stock-torch.nn stand-in with WavLM-Large\'s compute '
                                                                            'shape (7 strided convs + 24 transformer layers 1024/16/4096, random init)'
@@ -577,6 +611,10 @@ def main():
                    final_G_loss=g_loss, launch=launch, ms_per_step_median=ms_median,
                    timing='value / ms_per_step: K steps between two device synchronisations (the contract); ms_per_step_median: median of the K '
                           'per-step HIP-event timings inside that region')
+        out['arithmetic'] = dict(default=DTYPE_DEFAULT, this_run=DTYPE_EXACT if args.exact_fp32 else DTYPE_DEFAULT,
+                                 exact_fp32_ms_per_step=step_ms if args.exact_fp32 else fp32_ms,
+                                 note='op-level error vs float64 of the split-bf16 kernels: 1.2e-7 (weight-grad) / 3.0e-7 (forward), of the fp32 MFMA '
+                                      'kernels they replace: 1.6e-7 / 3.5e-7 (tests/test_kernel_instances_gpu.py, 2e-5 gate); --exact-fp32 selects the latter')
         if dp_info is not None:
             out['data_parallel'] = dp_info
         if ssl:

@@ -143,13 +143,15 @@ void tdvc_fold_reset(void* stream);
  *   instantiations launched; tdvc_debug_trace_dump copies them ('\n'-separated, NUL-terminated) and returns the size needed. */
 void tdvc_set_force_generic(int on);
 void tdvc_debug_force_tile(int cfg);
-void tdvc_debug_knob(int which, int value); /* tuning knobs for A/B measurements: 0 = XCD-aware block order of the lean conv kernel (1 = on; default 0: measured null on this path); 3 = one block per CU in the fused conditioning backward (diagnostic); 4 = 1: no sample folding of short sequences (T = 16 / 32) in the lean conv kernel; 5 = 1: exact-fp32 MFMA instead of the split-bf16 x6 weight-grad kernel (conv_wgrad_x6.hip); 6 = 1: tdvc_conv_fwd_x6 always answers TDVC_EUNSUPPORTED */
+void tdvc_debug_knob(int which, int value); /* tuning knobs for A/B measurements: 0 = XCD-aware block order of the lean conv kernel (1 = on; default 0: measured null on this path); 3 = one block per CU in the fused conditioning backward (diagnostic); 4 = 1: no sample folding of short sequences (T = 16 / 32) in the lean conv kernel; 5 = 1: exact-fp32 MFMA instead of the split-bf16 x6 weight-grad kernel (conv_wgrad_x6.hip); 6 = 1: tdvc_conv_fwd_x6 always answers TDVC_EUNSUPPORTED; 7 = 1: two instead of three resident blocks per CU in the x6 weight-grad's plan */
 void tdvc_debug_lds_cap(int bytes);   /* tuning knob: LDS bytes per block the lean kernel's chunk-size choice may use (0 = built-in) */
 void tdvc_debug_trace(int on);
 size_t tdvc_debug_trace_dump(char* buf, size_t cap);
 /* TEST-ONLY: fill the LDS of every CU with the bit pattern `word` (e.g. 0xFFFFFFFF = a NaN) so that a kernel which reads
  * LDS it never wrote shows up as NaN in its output instead of passing on whatever finite data the last kernel left. */
 int tdvc_debug_poison_lds(uint32_t word, void* stream);
+/* TOOLS-ONLY: an empty dispatch (pmc_marker_kernel) that separates table entries in a rocprofv3 trace (tools/microbench_kernels.py) */
+int tdvc_debug_marker(void* stream);
 
 /* Fused forward of one FiLM residual block (model/generator.py:96-111), narrow long-sequence case (C == 16, T % 4 == 0, T >= 512,
  * reflect padding (K-1)*dilation/2, 16-byte aligned operands; TDVC_EUNSUPPORTED otherwise -> run the two tdvc_conv_fwd calls):

@@ -114,6 +114,7 @@ SIGNATURES = {
     'tdvc_fold_flush': (_i, [C.c_void_p]),
     'tdvc_fold_reset': (None, [C.c_void_p]),
     'tdvc_debug_poison_lds': (_i, [C.c_uint32, C.c_void_p]),
+    'tdvc_debug_marker': (_i, [C.c_void_p]),
     'tdvc_debug_trace': (None, [_i]),
     'tdvc_debug_trace_dump': (C.c_size_t, [C.c_char_p, C.c_size_t]),
     'tdvc_weight_norm_fwd': (_i, [_vp, _vp, _vp, _vp, _vp, _vp, _i, _vp]),

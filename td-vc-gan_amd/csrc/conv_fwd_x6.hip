@@ -36,7 +36,7 @@ struct FwdX6P {
 
 constexpr int FX_NT = 128;              // steps per block
 constexpr int FX_CP = 160;              // padded channel count of the weight planes (5 chunks of 32)
-constexpr int FX_RS = 40;               // bf16 row stride of both LDS images: 80 B -> 16 rows start on 16 distinct 4-bank groups
+constexpr int FX_RS = 32;               // bf16 row length of both LDS images: 64 B, no padding; the 16-byte slot q of row r lives at slot q ^ ((r >> 1) & 3)
 constexpr int FX_PR = 34;               // rows of one phase plane: window index s = position - (n0 - 4) = 4 row + phase, s in [3, 132]
 constexpr int FX_XPL = 4 * FX_PR * FX_RS;   // one piece of the activation tile: [phase][row][FX_RS]
 constexpr int FX_WREC = 3 * 32 * 3 * 4;     // 16-byte vectors of one weight record (32 output channels x one chunk): [piece][co][tap][4]
@@ -50,21 +50,26 @@ __device__ __forceinline__ void split1(const float f, unsigned& h, unsigned& m, 
   const float r2 = r1 - __builtin_bit_cast(float, m);
   l = __builtin_bit_cast(unsigned, r2);
 }
+// LDS element offset of slot q (8 bf16) of row r. ds_read_b128 serves a wave in four NON-contiguous 16-lane groups ({0-3, 12-15, 20-27}, ...:
+// MI355X_MICROARCH.md, LDS), so a group mixes rows of two k-quarters: padded 80-byte rows made every group 2-way conflicting
+// (SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50 in profiles/r03_pmc.txt). With this XOR any 16 consecutive rows read by lanes
+// (row = base + (lane & 15), q = lane >> 4) touch 16 distinct 4-bank slots in every group, for every base (tools/lds_swizzle_check.py).
+__device__ __forceinline__ int swz(int r, int q) { return r * FX_RS + 8 * (q ^ ((r >> 1) & 3)); }
 __device__ __forceinline__ unsigned pack_hi(unsigned a, unsigned b) {      // {upper half of a, upper half of b}: a in the low 16 bits
   return __builtin_amdgcn_perm(b, a, 0x07060302u);
 }
 
 template <int CO_TILES>
-__global__ __launch_bounds__(256, 2) void conv_fwd_x6_kernel(const FwdX6P p) {
+__global__ __launch_bounds__(256, CO_TILES == 2 ? 3 : 2) void conv_fwd_x6_kernel(const FwdX6P p) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
   constexpr int MT = 16 * CO_TILES;
   constexpr int CB = MT / 32;                         // weight records per chunk
   constexpr int CT2 = CO_TILES / 2;                   // output-channel tiles of one wave
-  constexpr int WPL = MT * 3 * FX_RS;                 // elements of one weight piece in LDS: [co][tap][FX_RS]
+  constexpr int WPL = MT * 3 * FX_RS;                 // elements of one weight piece in LDS: [tap][co][FX_RS] (swizzled rows)
   constexpr int WNV = CB * FX_WREC;                   // 16-byte vectors of a weight chunk
   constexpr int WPT = (WNV + 255) / 256;
   unsigned short* xt = smem16;                        // [3 pieces][4 phases][FX_PR][FX_RS]
-  unsigned short* ws = smem16 + 3 * FX_XPL;           // [3 pieces][MT][3][FX_RS]
+  unsigned short* ws = smem16 + 3 * FX_XPL;           // [3 pieces][3 taps][MT][FX_RS]; both images start on multiples of 8 rows
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wt = wave & 1, wc = wave >> 1;
@@ -103,7 +108,8 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6_kernel(const FwdX6P p) {
     const int e = tid + i * 256;
     const int cb = e / FX_WREC, er = e - cb * FX_WREC;
     const int row = er >> 2, pc = row / 96, rr = row - pc * 96;            // rr = co * 3 + tap
-    wl[i] = pc * WPL + (cb * 96 + rr) * FX_RS + 8 * (er & 3);
+    const int co = rr / 3, j = rr - co * 3;
+    wl[i] = pc * WPL + swz(j * MT + cb * 32 + co, er & 3);
   }
 
   f32x4 xr[4];
@@ -140,7 +146,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6_kernel(const FwdX6P p) {
         const float f = fmaxf(f0, f0 * p.slope);      // slope in (0, 1]: LeakyReLU; 1: identity
         split1(f, hh[e], mm[e], ll[e]);
       }
-      const int off = (k * FX_PR + xv + 1) * FX_RS + 4 * c4;
+      const int off = swz(k * FX_PR + xv + 1, c4 >> 1) + 4 * (c4 & 1);
       *reinterpret_cast<u32x2*>(xt + 0 * FX_XPL + off) = (u32x2){pack_hi(hh[0], hh[1]), pack_hi(hh[2], hh[3])};
       *reinterpret_cast<u32x2*>(xt + 1 * FX_XPL + off) = (u32x2){pack_hi(mm[0], mm[1]), pack_hi(mm[2], mm[3])};
       *reinterpret_cast<u32x2*>(xt + 2 * FX_XPL + off) = (u32x2){pack_hi(ll[0], ll[1]), pack_hi(ll[2], ll[3])};
@@ -148,7 +154,7 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6_kernel(const FwdX6P p) {
     if (tid < 64) {                                   // halo: window index 3 (phase 3, row 0) | 132 (phase 0, row 33)
       unsigned h, m, l;
       split1(fmaxf(hr, hr * p.slope), h, m, l);
-      const int off = ((tid & 32) ? (FX_PR - 1) : 3 * FX_PR) * FX_RS + (tid & 31);
+      const int off = swz((tid & 32) ? (FX_PR - 1) : 3 * FX_PR, (tid & 31) >> 3) + (tid & 7);
       xt[0 * FX_XPL + off] = (unsigned short)(h >> 16);
       xt[1 * FX_XPL + off] = (unsigned short)(m >> 16);
       xt[2 * FX_XPL + off] = (unsigned short)(l >> 16);
@@ -171,14 +177,14 @@ __global__ __launch_bounds__(256, 2) void conv_fwd_x6_kernel(const FwdX6P p) {
       for (int ct = 0; ct < CT2; ++ct)
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc)
-          af[ct][pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ws + pc * WPL + ((16 * (wc * CT2 + ct) + ln) * 3 + j) * FX_RS + 8 * g));
+          af[ct][pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ws + pc * WPL + swz(j * MT + 16 * (wc * CT2 + ct) + ln, g)));
 #pragma unroll
       for (int n = 0; n < 4; ++n) {
         const int m = n + j + 3;
         bf16x8 bf[3];
 #pragma unroll
         for (int pc = 0; pc < 3; ++pc)
-          bf[pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xt + pc * FX_XPL + ((m & 3) * FX_PR + 16 * wt + ln + (m >> 2)) * FX_RS + 8 * g));
+          bf[pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xt + pc * FX_XPL + swz((m & 3) * FX_PR + 16 * wt + ln + (m >> 2), g)));
 #pragma unroll
         for (int ct = 0; ct < CT2; ++ct) {            // smallest products first
           f32x4 cc = acc[ct][n];

@@ -682,7 +682,7 @@ hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st) {
   // short sequences: several samples per 64-column tile (kernel comment at FOLD)
   p.fold = 1; p.seg = 0; p.Bn = B;
   const bool fold_combo = (xfk == LXF_ACT && (epi == EPI_FWD || epi == EPI_PLAIN)) || (xfk == LXF_MASK_LRELU && epi == EPI_PLAIN);
-  if (g_knob[4] == 0 && g_force_tile < 0 && NT == 64 && R >= 32 && (p.T == 16 || p.T == 32) && B >= 64 / p.T && p.vec && !p.reflect && p.mirror == 0 && fold_combo &&
+  if (g_knob[4] == 0 && g_force_tile < 0 && NT == 64 && R >= 32 && (p.T == 16 || p.T == 32) && p.Cin % 16 == 0 && B >= 64 / p.T && p.vec && !p.reflect && p.mirror == 0 && fold_combo &&
       !p.sbits && !p.mbits && (!p.aux || p.aux_bs == p.x_bs) && (long)(64 / p.T) * p.x_bs < (1L << 28)) {
     p.fold = 64 / p.T;
     p.seg = ((p.T + hi - lo) + 3) / 4 * 4;

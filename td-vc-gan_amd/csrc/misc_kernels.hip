@@ -70,6 +70,13 @@ extern "C" int tdvc_debug_poison_lds(uint32_t word, void* stream) {
   TDVC_CHECK_LAUNCH();
   return TDVC_OK;
 }
+namespace tdvc { __global__ void pmc_marker_kernel(int*) {} }
+// TOOLS-ONLY: an empty dispatch that separates the launches of one table entry from the next in a rocprofv3 trace (tools/pmc_traffic.py)
+extern "C" int tdvc_debug_marker(void* stream) {
+  hipLaunchKernelGGL(tdvc::pmc_marker_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, (int*)nullptr);
+  TDVC_CHECK_LAUNCH();
+  return TDVC_OK;
+}
 extern "C" void tdvc_debug_trace(int on) {
   std::lock_guard<std::mutex> lk(tdvc::g_trace_mu);
   if (on == 1) tdvc::g_trace_names.clear();

@@ -29,17 +29,22 @@ def per_entry(manifest, d):
         k = int(r['Dispatch_Id'])
         disp.setdefault(k, (norm(r['Kernel_Name']), {}))[1][r['Counter_Name']] = float(r['Counter_Value'])
     seq = [v for _, v in sorted(disp.items())]
-    wanted = set(n for e in manifest for n in e['kernels'])
-    seq = [v for v in seq if v[0] in wanted]
-    out, pos = {}, 0
-    for e in manifest:
-        n = e['calls'] * len(e['kernels'])
-        chunk = seq[pos:pos + n]
-        pos += n
-        names = {v[0] for v in chunk}
-        if len(chunk) < n or not names <= set(e['kernels']):
-            raise SystemExit(f'{d}: dispatch sequence does not match the manifest at {e["op"]!r} ({len(chunk)}/{n}, {names})')
-        main = [v[1] for v in chunk if v[0] == e['kernels'][0]][-max(1, e['calls'] - 3):]      # drop the warm-up launches
+    # every entry ends with one pmc_marker_kernel dispatch (bench.kernel_table with a manifest): segment i <-> manifest[i]
+    segs, cur = [], []
+    for v in seq:
+        if v[0] == 'pmc_marker_kernel':
+            segs.append(cur); cur = []
+        else:
+            cur.append(v)
+    segs = segs[1:]      # the first marker closes the recorded training iteration that precedes the table
+    if len(segs) != len(manifest):
+        raise SystemExit(f'{d}: {len(segs)} marker-delimited segments for {len(manifest)} manifest entries')
+    out = {}
+    for e, seg in zip(manifest, segs):
+        mine = [v[1] for v in seg if v[0] == e['kernels'][0]]
+        if len(mine) < 4:
+            raise SystemExit(f'{d}: only {len(mine)} dispatches of {e["kernels"][0]} in the segment of {e["op"]!r}: {sorted({v[0] for v in seg})}')
+        main = mine[-max(1, len(mine) - 3):]      # drop the warm-up launches
         agg = collections.defaultdict(float)
         for c in main:
             for k, v in c.items():
