@@ -698,7 +698,10 @@ hipError_t launch_conv_lean(LeanP p, int B, int xfk, int epi, hipStream_t st) {
   // ran 22 % slower; the other tiles gain 0-6 % (tools/tile_sweep.py, profiles/r02_b_tile_sweep.txt).
   const size_t lds_cap = g_lds_cap > 0 ? (size_t)g_lds_cap : (size_t)((cfg == 4 ? 40 : 52) * 1024);   // 4 resident 64 x 64 blocks
   int Cc = 0;
-  for (int cc = 4; cc <= 32 && cc <= ((p.Cin + 3) / 4) * 4; cc += 4) {
+  // 16-row tiles over a long reduction (the discriminators' 1024 -> 16 heads: 32 serial chunks of 32 channels on 32-64 blocks, each
+  // chunk one exposed load latency: 77 us for 0.2 GFLOP) take chunks of up to 64 channels when the prefetch registers hold them
+  const int cc_cap = (MT == 16 && p.Cin >= 256) ? 64 : 32;
+  for (int cc = 4; cc <= cc_cap && cc <= ((p.Cin + 3) / 4) * 4; cc += 4) {
     int xrp, xnp, wrp, wnp;
     walk_geometry(cc, p.span / 4, &xrp, &xnp);
     walk_geometry(MT, p.K * cc / 4, &wrp, &wnp);
