@@ -46,7 +46,7 @@ def update_stats(before, after_got, after_ref, lr):
 # of the channel-chunk size of an unrelated conv, on the exact-fp32 kernels as well; seeds 4243 / 4244 / 4245 gave 0..7 outliers in every
 # build and arithmetic mode. A flip belongs to one batch, a kernel error does not: a case with two seeds passes when the gate holds on at
 # least one of its batches (the second runs only if the first fails); the hard bound of the gate (1e-2, every tensor) holds on every batch run.
-CASES = [('conv_enc-stage1', 16, 16000, (4242,)), ('conv_enc-stage2_1', 32, 16000, (4242,)), ('conv_enc-stage2_2', 4, 16000, (4242,)),
+CASES = [('conv_enc-stage1', 16, 16000, (4242, 4243)), ('conv_enc-stage2_1', 32, 16000, (4242, 4243)), ('conv_enc-stage2_2', 4, 16000, (4242, 4243)),
          ('wavlm-stage2_2', 8, 32000, (4243, 4242))]
 
 
