@@ -169,7 +169,7 @@ def kernel_table(pkg, dev, classes, step_ms, iters=20, manifest=None, only_ops=N
                  unit='GB/s' if bound == 'hbm' else 'TFLOP/s', algorithmic_bytes=alg_bytes, algorithmic_flops=flops,
                  rotation_bytes=rot_bytes)
         e['frac'] = e['achieved'] / e['peak']
-        if '_x6_kernel' in name:      # split-bf16 x6: six bf16 MFMA products per fp32-equivalent product; both accountings are shown
+        if '_x6_kernel' in name and 'film_cond_fwd' not in name:      # split-bf16 x6: six bf16 MFMA products per fp32-equivalent product; both accountings are shown
             e['bf16_pipe'] = dict(executed_tflops=6.0 * ach_f, peak=MFMA_BF16_PEAK_TF, frac=6.0 * ach_f / MFMA_BF16_PEAK_TF,
                                   note='`achieved` / `frac` above count the fp32-equivalent product once and price it against the fp32 MFMA '
                                        'peak (what the exact-fp32 kernel it replaces is priced against); this is the same launch as executed '
@@ -340,6 +340,32 @@ def kernel_table(pkg, dev, classes, step_ms, iters=20, manifest=None, only_ops=N
                  'LeakyReLU mask + cond_var.0 backward (dexc, dW window, dk3), one launch (+ slab fold)')
         return add(label, n, 4.0 * words + 4.0 * (wt2.numel() + nc * nv * 3), 2.0 * Bc * T * nc * (C2 * 3 + 2 * nv * 3), calls, bufs.bytes_per_rotation)
 
+    def cond_fwd_x6_class(rec, n):
+        """Conditioning forward in one launch (conv_fwd_x6.hip, film_cond_fwd_x6_kernel): cond_var.0's excitation window on the fly + cond_var.2
+        in split-bf16 x6. Algorithmic bytes: exc and k3 read; cv0 (fp32, for the backward), its sign bits and gb written; weights."""
+        _, Bc, T, nc, nv, C2, has_bits = rec
+        w0 = torch.randn(nc, nc, 3, device=dev) / (nc * 3) ** 0.5
+        w2 = torch.randn(C2, nc, 3, device=dev) / (nc * 3) ** 0.5
+        b2 = torch.randn(C2, device=dev) * 0.1
+        spec2 = ops.ConvSpec(nc, C2, 3, 1, 1, 1, 1, False)
+        spec2.slot = arena.ConvSlot(w2.data_ptr(), b2.data_ptr(), 0, 0, True, None, 0)
+        planes = ops._weight_planes_x6(spec2, dev)
+        bufs = Bufs(torch, dev, dict(exc=(Bc, nv, T), k3=(Bc, nc, 3), cv0=(Bc, nc, T), gb=(Bc, C2, T)))
+        bitbufs = [torch.empty((Bc, nc, T // 32), dtype=torch.int32, device=dev) if has_bits else None for _ in bufs.sets]
+        st = torch.cuda.current_stream(dev).cuda_stream
+        calls, args = [], []
+        for s, bw in zip(bufs.sets, bitbufs):
+            a = L.FilmCondArgs(Bc, T, nc, nv, C2, s['exc'].data_ptr(), s['exc'].stride(0), w0.data_ptr(), s['k3'].data_ptr(), w2.data_ptr(), b2.data_ptr(),
+                               s['cv0'].data_ptr(), s['cv0'].stride(0), s['gb'].data_ptr(), s['gb'].stride(0), 0.2)
+            args.append(a)
+            calls.append(lambda a=a, bw=bw: L.check(lib.tdvc_film_cond_fwd_x6(C.byref(a), planes.data_ptr(), bw.data_ptr() if bw is not None else None,
+                                                                              bw.stride(0) if bw is not None else 0, st)))
+        keep[:] = [w0, w2, b2, spec2, planes, bufs, bitbufs, args]
+        words = Bc * T * (nv + nc + C2 + (nc / 32.0 if has_bits else 0.0))
+        label = (f'FiLM conditioning forward 8->{nc}->{C2} T={T} B={Bc}: cond_var.0 excitation window + LeakyReLU + cond_var.2 (split-bf16 x6), one launch; '
+                 'cv0' + (' + sign bits' if has_bits else '') + ' stored for the backward')
+        return add(label, n, 4.0 * words + 4.0 * (w2.numel() + nc * nv * 3 + Bc * nc * 3), 2.0 * Bc * T * nc * 3 * (C2 + nv), calls, bufs.bytes_per_rotation)
+
     def cond0_bwd_class(rec, n):
         _, Bc, T, nc, nv, has_dexc, want_w = rec
         w0 = torch.randn(nc, nc, 3, device=dev) / (nc * 3) ** 0.5
@@ -358,7 +384,7 @@ def kernel_table(pkg, dev, classes, step_ms, iters=20, manifest=None, only_ops=N
         return add(f'FiLM cond_var.0 backward (dexc + dW window + dk3) 136ch T={T} B={Bc} (+ slab fold)', n, 4.0 * Bc * T * (nc + 2 * nv),
                    2.0 * Bc * T * nc * nv * 3 * 2, calls, bufs.bytes_per_rotation)
 
-    handlers = dict(fwd=conv_class, dgrad=conv_class, wgrad=conv_class, fwd_x6=fwd_x6_class, film_block_fwd=film_block_class, film_cond_bwd=cond_bwd_class,
+    handlers = dict(fwd=conv_class, dgrad=conv_class, wgrad=conv_class, fwd_x6=fwd_x6_class, film_cond_fwd_x6=cond_fwd_x6_class, film_block_fwd=film_block_class, film_cond_bwd=cond_bwd_class,
                     film_cond0_bwd=cond0_bwd_class)
     north = None
     for rec, n in sorted(classes.items(), key=lambda kv: str(kv[0])):

@@ -186,6 +186,11 @@ typedef struct {
   float slope;
 } tdvc_film_cond_args;
 int tdvc_film_cond_fwd(const tdvc_film_cond_args* a, void* stream);
+/* The same forward with cond_var.2 in split-bf16 x6 arithmetic (conv_fwd_x6.hip) and cond_var.0's excitation window computed per tile inside
+ * that kernel: cv0 is written once (for the backward pass) and never read back, its sign bits (cv0_sign_bits [B][n_cond][T/32], optional,
+ * T % 32 == 0) come out of the same registers. w2_planes = tdvc_conv_x6_weight_planes of cond_var.2's weight (a->w2 is not read).
+ * Needs n_var == 8, 64 < n_cond <= 160, n_cond % 4 == 0, C2 % 32 == 0, T >= 128, T % 4 == 0; TDVC_EUNSUPPORTED otherwise. */
+int tdvc_film_cond_fwd_x6(const tdvc_film_cond_args* a, const void* w2_planes, uint32_t* cv0_sign_bits, int64_t bits_bs, void* stream);
 
 /* Backward of cond_var.0 in the split formulation, everything that consumes d_cv0 = dL/d(cond_var.0 output) in one pass:
  * dexc (input-grad wrt the excitation), the excitation window of dW (accumulated into dw0, module layout

@@ -97,6 +97,7 @@ SIGNATURES = {
     'tdvc_conv_x6_weight_planes': (_i, [_vp, C.c_int32, C.c_int32, C.c_int32, _vp, _vp]),
     'tdvc_conv_fwd_x6': (_i, [C.POINTER(ConvDesc), C.POINTER(ConvFwdArgs), _vp, _vp]),
     'tdvc_film_cond_fwd': (_i, [C.POINTER(FilmCondArgs), _vp]),
+    'tdvc_film_cond_fwd_x6': (_i, [C.POINTER(FilmCondArgs), C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p]),
     'tdvc_film_cond0_bwd': (_i, [C.POINTER(FilmCond0BwdArgs), _vp]),
     'tdvc_film_cond_bwd': (_i, [C.POINTER(FilmCondBwdArgs), _vp]),
     'tdvc_film_cond_bwd_workspace': (C.c_size_t, [C.c_int32, C.c_int32, C.c_int32, C.c_int32]),

@@ -218,6 +218,251 @@ __global__ __launch_bounds__(256, CO_TILES == 2 ? 3 : 2) void conv_fwd_x6_kernel
   PROF_END
 }
 
+// ---------------------------------------------------------------------------------------------------------------------------
+// The same forward with cond_var.0's excitation window computed on the fly (FiLM conditioning, model/generator.py:86-92):
+//     cv0[c][t] = k3[c][t == 0 | interior | t == T - 1] + sum_{ce < 8, j} W0x[c][ce][j] * exc[ce][t + j - 1]
+//     gb = cond_var.2(LeakyReLU(cv0))
+// Per 32-channel chunk of the reduction the block computes its own cv0 tile (fp32 MFMA, K = 24) straight into the accumulator layout
+// of the permuted sub-tiles, so that (a) the fp32 intermediate goes to HBM once, as 4 rows x 256 B stores, for the backward pass,
+// (b) its sign bits are packed in registers, (c) LeakyReLU + the bf16 split feed the x6 product's LDS tile: the 136-channel tensor is
+// never read back by the forward (two launches: written by one, read by the next). The B operand of the small product (the
+// excitation window) does not depend on the chunk and stays in registers.
+struct CondX6P {
+  const float* exc; long exc_bs;        // [B][8][T]
+  const float* w0; int w0_rs, w0_off;   // W0x[c][k] = w0[c * w0_rs + w0_off + k], k = ce * 3 + j: 24 contiguous floats per row
+  const float* k3;                      // [B][nc][3], cond_var.0's bias included
+  const unsigned short* wp;             // cond_var.2 weight pieces (tdvc_conv_x6_weight_planes)
+  const float* bias;                    // cond_var.2 bias or null
+  float* cv0; long cv0_bs;              // [B][nc][T] or null
+  unsigned* bits; long bits_bs;         // [B][nc][T / 32] or null (T % 32 == 0)
+  float* y; long y_bs;                  // gb [B][Cout][T]
+  int T, Cin, Cout;                     // Cin = nc
+  float slope;
+};
+constexpr int FX_ESR = 36;              // row stride of one phase plane of the excitation tile (34 used)
+
+template <int CO_TILES>
+__global__ __launch_bounds__(256, 2) void film_cond_fwd_x6_kernel(const CondX6P p) {
+  extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
+  constexpr int MT = 16 * CO_TILES;
+  constexpr int CB = MT / 32;
+  constexpr int CT2 = CO_TILES / 2;
+  constexpr int WPL = MT * 3 * FX_RS;
+  constexpr int WNV = CB * FX_WREC;
+  constexpr int WPT = (WNV + 255) / 256;
+  unsigned short* xt = smem16;                        // [3 pieces][4 phases][FX_PR][FX_RS]
+  unsigned short* ws = smem16 + 3 * FX_XPL;           // [3 pieces][3 taps][MT][FX_RS]
+  float* es = reinterpret_cast<float*>(ws + 3 * WPL); // [8][4 phases][FX_ESR] excitation window [n0 - 4, n0 + 132), fp32
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wt = wave & 1, wc = wave >> 1;            // x6 product: step half, output-channel half
+  const int mt = wave & 1, grp = wave >> 1;           // cv0 product: 16-channel tile of the chunk, 64-step group
+  const int ln = lane & 15, g = lane >> 4;
+  const int T = p.T, n0 = blockIdx.x * FX_NT, r0 = blockIdx.y * MT, b = blockIdx.z;
+  const int nc = p.Cin, nchunk = (nc + 31) >> 5;
+  const bool writer = blockIdx.y == 0;                // every output-channel block computes cv0; one stores it
+  const srd_t wrs = make_srd(reinterpret_cast<const float*>(p.wp), (p.Cout >> 5) * 5 * FX_WREC * 16);
+
+  // ---- excitation tile -> LDS, phase planes
+  {
+    const srd_t ers = make_srd(p.exc + (long)b * p.exc_bs, 8 * T * 4);
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const int e = tid + i * 256;
+      if (e < 8 * 34) {
+        const int row = e / 34, v = e - row * 34, q = n0 - 4 + 4 * v;
+        const f32x4 x4 = buf_load4(ers, (q >= 0 && q < T) ? (row * T + q) * 4 : 0x7f000000);
+        es[(row * 4 + 0) * FX_ESR + v] = x4[0]; es[(row * 4 + 1) * FX_ESR + v] = x4[1];
+        es[(row * 4 + 2) * FX_ESR + v] = x4[2]; es[(row * 4 + 3) * FX_ESR + v] = x4[3];
+      }
+    }
+  }
+
+  f32x4 acc[CT2][4];
+#pragma unroll
+  for (int ct = 0; ct < CT2; ++ct)
+#pragma unroll
+    for (int n = 0; n < 4; ++n) acc[ct][n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  float bias[CT2][4];
+#pragma unroll
+  for (int ct = 0; ct < CT2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = r0 + 16 * (wc * CT2 + ct) + 4 * g + r;
+      bias[ct][r] = (p.bias && co < p.Cout) ? p.bias[co] : 0.f;
+    }
+  int wl[WPT];
+#pragma unroll
+  for (int i = 0; i < WPT; ++i) {
+    const int e = tid + i * 256;
+    const int cb = e / FX_WREC, er = e - cb * FX_WREC;
+    const int row = er >> 2, pc = row / 96, rr = row - pc * 96;
+    const int co = rr / 3, j = rr - co * 3;
+    wl[i] = pc * WPL + swz(j * MT + cb * 32 + co, er & 3);
+  }
+
+  __syncthreads();                                    // the excitation tile is in LDS
+  // B operand of the cv0 product, chunk invariant: lane (column ln, k-lane g) of k-step s holds E'[k = 4s + g][step], k = ce * 3 + j,
+  // E'[(ce, j)][t] = exc[ce][t + j - 1]. Column ln of sub-tile n is step n0 + 64 grp + 4 ln + n = window index 64 grp + 4 ln + (n + j + 3)
+  float ef[4][6], eh[6];
+#pragma unroll
+  for (int s = 0; s < 6; ++s) {
+    const int k = 4 * s + g, ce = k / 3, j = k - 3 * ce;
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      const int m = n + j + 3;
+      ef[n][s] = es[(ce * 4 + (m & 3)) * FX_ESR + 16 * grp + ln + (m >> 2)];
+    }
+    // halo columns (waves of group 0): column 0 = step n0 - 1 (window index j + 2), column 1 = step n0 + 128 (window index j + 131)
+    const int mh = (ln == 1) ? j + 131 : j + 2;
+    eh[s] = es[(ce * 4 + (mh & 3)) * FX_ESR + (mh >> 2)];
+  }
+
+  const srd_t w0rs = make_srd(p.w0, (nc - 1) * p.w0_rs * 4 + (p.w0_off + 24) * 4);
+  const srd_t k3rs = make_srd(p.k3 + (long)b * nc * 3, nc * 3 * 4);
+  float aw[6];
+  f32x4 k3v[3];
+  u32x4 wr[WPT];
+  auto issue = [&](int c) {
+    const int ch = c * 32 + 16 * mt + ln;             // A operand row of this lane
+#pragma unroll
+    for (int s = 0; s < 6; ++s)
+      aw[s] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(w0rs, ch < nc ? (ch * p.w0_rs + p.w0_off + 4 * s + g) * 4 : 0x7f000000, 0, 0));
+    const int c4 = c * 32 + 16 * mt + 4 * g;          // this lane's 4 output channels: 12 contiguous floats of k3
+#pragma unroll
+    for (int i = 0; i < 3; ++i) k3v[i] = buf_load4(k3rs, c4 < nc ? (c4 * 3 + 4 * i) * 4 : 0x7f000000);
+#pragma unroll
+    for (int i = 0; i < WPT; ++i)
+      wr[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(wrs, (tid + i * 256 < WNV) ? (tid + i * 256) * 16 : 0x7f000000,
+                                                                              (blockIdx.y * 5 + c) * (WNV * 16), 0));
+  };
+  issue(0);
+
+  const int pos0 = n0 + 64 * grp + 4 * ln;            // first of this lane's 4 consecutive steps
+  const int hpos = (ln == 1) ? n0 + FX_NT : n0 - 1;
+  for (int c = 0; c < nchunk; ++c) {
+    __syncthreads();                                  // the previous chunk's fragments are consumed
+    // ---- cv0 chunk: D[channel 4g + r][step column ln] per sub-tile n
+    f32x4 cv[4], ch4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int n = 0; n < 4; ++n) cv[n] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < 6; ++s) {
+#pragma unroll
+      for (int n = 0; n < 4; ++n) cv[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[s], ef[n][s], cv[n], 0, 0, 0);
+      if (grp == 0) ch4 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[s], eh[s], ch4, 0, 0, 0);
+    }
+    const int cbase = c * 32 + 16 * mt + 4 * g;       // channels cbase + r
+    const float kf[12] = {k3v[0][0], k3v[0][1], k3v[0][2], k3v[0][3], k3v[1][0], k3v[1][1], k3v[1][2], k3v[1][3],
+                          k3v[2][0], k3v[2][1], k3v[2][2], k3v[2][3]};
+    float v[4][4];                                    // [n][r]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const float c0v = cv[0][r], c1v = cv[1][r], c2v = cv[2][r], c3v = cv[3][r];
+      const float cc[4] = {c0v, c1v, c2v, c3v};
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const int pos = pos0 + n;
+        const float bs = pos == 0 ? kf[3 * r] : (pos == T - 1 ? kf[3 * r + 2] : kf[3 * r + 1]);
+        v[n][r] = cc[n] + bs;
+      }
+    }
+    const bool own = pos0 < T;                        // T % 4 == 0: the lane's 4 steps are inside or outside together
+    if (writer && own && cbase < nc) {
+      if (p.cv0) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          *reinterpret_cast<f32x4*>(p.cv0 + (long)b * p.cv0_bs + (long)(cbase + r) * T + pos0) = (f32x4){v[0][r], v[1][r], v[2][r], v[3][r]};
+      }
+      if (p.bits) {                                   // word = 32 steps of one channel = the nibbles of 8 consecutive lanes
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          unsigned w = (v[0][r] > 0.f ? 1u : 0u) | (v[1][r] > 0.f ? 2u : 0u) | (v[2][r] > 0.f ? 4u : 0u) | (v[3][r] > 0.f ? 8u : 0u);
+          w <<= 4 * (ln & 7);
+          w |= __shfl_xor(w, 1); w |= __shfl_xor(w, 2); w |= __shfl_xor(w, 4);
+          if ((ln & 7) == 0) p.bits[(long)b * p.bits_bs + (long)(cbase + r) * (T >> 5) + ((n0 + 64 * grp) >> 5) + (ln >> 3)] = w;
+        }
+      }
+    }
+    // LeakyReLU, zero outside the sequence (cond_var.2's zero padding), split, 8-byte store of the lane's 4 channels per step
+#pragma unroll
+    for (int n = 0; n < 4; ++n) {
+      unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float f0 = own ? v[n][r] : 0.f;
+        split1(fmaxf(f0, f0 * p.slope), hh[r], mm[r], ll[r]);
+      }
+      const int off = swz(n * FX_PR + 16 * grp + ln + 1, 2 * mt + (g >> 1)) + 4 * (g & 1);
+      *reinterpret_cast<u32x2*>(xt + 0 * FX_XPL + off) = (u32x2){pack_hi(hh[0], hh[1]), pack_hi(hh[2], hh[3])};
+      *reinterpret_cast<u32x2*>(xt + 1 * FX_XPL + off) = (u32x2){pack_hi(mm[0], mm[1]), pack_hi(mm[2], mm[3])};
+      *reinterpret_cast<u32x2*>(xt + 2 * FX_XPL + off) = (u32x2){pack_hi(ll[0], ll[1]), pack_hi(ll[2], ll[3])};
+    }
+    if (grp == 0 && ln < 2) {                         // halo steps: window index 3 (phase 3, row 0) | 132 (phase 0, row 33)
+      const bool hin = hpos >= 0 && hpos < T;
+      unsigned hh[4], mm[4], ll[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const float bs = hpos == 0 ? kf[3 * r] : (hpos == T - 1 ? kf[3 * r + 2] : kf[3 * r + 1]);
+        const float hv = ch4[r];
+        const float f0 = hin ? hv + bs : 0.f;
+        split1(fmaxf(f0, f0 * p.slope), hh[r], mm[r], ll[r]);
+      }
+      const int off = swz(ln == 1 ? FX_PR - 1 : 3 * FX_PR, 2 * mt + (g >> 1)) + 4 * (g & 1);
+      *reinterpret_cast<u32x2*>(xt + 0 * FX_XPL + off) = (u32x2){pack_hi(hh[0], hh[1]), pack_hi(hh[2], hh[3])};
+      *reinterpret_cast<u32x2*>(xt + 1 * FX_XPL + off) = (u32x2){pack_hi(mm[0], mm[1]), pack_hi(mm[2], mm[3])};
+      *reinterpret_cast<u32x2*>(xt + 2 * FX_XPL + off) = (u32x2){pack_hi(ll[0], ll[1]), pack_hi(ll[2], ll[3])};
+    }
+#pragma unroll
+    for (int i = 0; i < WPT; ++i)
+      if (tid + i * 256 < WNV) *reinterpret_cast<u32x4*>(ws + wl[i]) = wr[i];
+    __syncthreads();
+    if (c + 1 < nchunk) issue(c + 1);
+
+#pragma unroll
+    for (int j = 0; j < 3; ++j) {
+      bf16x8 af[CT2][3];
+#pragma unroll
+      for (int ct = 0; ct < CT2; ++ct)
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+          af[ct][pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(ws + pc * WPL + swz(j * MT + 16 * (wc * CT2 + ct) + ln, g)));
+#pragma unroll
+      for (int n = 0; n < 4; ++n) {
+        const int m = n + j + 3;
+        bf16x8 bf[3];
+#pragma unroll
+        for (int pc = 0; pc < 3; ++pc)
+          bf[pc] = __builtin_bit_cast(bf16x8, *reinterpret_cast<const u32x4*>(xt + pc * FX_XPL + swz((m & 3) * FX_PR + 16 * wt + ln + (m >> 2), g)));
+#pragma unroll
+        for (int ct = 0; ct < CT2; ++ct) {
+          f32x4 cc = acc[ct][n];
+          cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ct][2], bf[0], cc, 0, 0, 0);
+          cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ct][0], bf[2], cc, 0, 0, 0);
+          cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ct][1], bf[1], cc, 0, 0, 0);
+          cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ct][1], bf[0], cc, 0, 0, 0);
+          cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ct][0], bf[1], cc, 0, 0, 0);
+          cc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[ct][0], bf[0], cc, 0, 0, 0);
+          acc[ct][n] = cc;
+        }
+      }
+    }
+  }
+
+  const int t0 = n0 + 64 * wt + 4 * ln;
+#pragma unroll
+  for (int ct = 0; ct < CT2; ++ct)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = r0 + 16 * (wc * CT2 + ct) + 4 * g + r;
+      if (co < p.Cout && t0 < T) {
+        const float bs = bias[ct][r];
+        const float v0 = acc[ct][0][r], v1 = acc[ct][1][r], v2 = acc[ct][2][r], v3 = acc[ct][3][r];
+        *reinterpret_cast<f32x4*>(p.y + (long)b * p.y_bs + (long)co * T + t0) = (f32x4){v0 + bs, v1 + bs, v2 + bs, v3 + bs};
+      }
+    }
+}
+
 __host__ __device__ __forceinline__ int x6_mt(int Cout) { return (Cout % 64 == 0) ? 64 : 32; }      // output channels per block
 
 // fp32 weights [Cout][Cin][3] -> [Cout / MT][5 chunks][MT / 32 records][piece][32 co][tap][32 ci] bf16 pieces (zero for channels >= Cin):
@@ -276,6 +521,35 @@ extern "C" int tdvc_conv_fwd_x6(const tdvc_conv_desc* d, const tdvc_conv_fwd_arg
     auto k = conv_fwd_x6_kernel<2>;
     TDVC_BIG_LDS_ONCE(k); TDVC_TRACE(k);
     hipLaunchKernelGGL(k, dim3(nt, d->Cout / 32, d->B), dim3(256), (size_t)(3 * FX_XPL + 3 * 32 * 3 * FX_RS) * 2, st, p);
+  }
+  TDVC_CHECK_LAUNCH();
+  return TDVC_OK;
+}
+
+extern "C" int tdvc_film_cond_fwd_x6(const tdvc_film_cond_args* a, const void* w2_planes, uint32_t* cv0_sign_bits, int64_t bits_bs, void* stream) {
+  if (!a || !a->exc || !a->w0 || !a->k3 || !a->gb || !w2_planes) return tdvc_fail(TDVC_EINVAL, "film_cond_fwd_x6: null pointer");
+  const bool shape = a->n_var == 8 && (a->n_cond & 3) == 0 && a->n_cond > 64 && a->n_cond <= FX_CP && a->C2 >= 32 && a->C2 % 32 == 0 && a->T >= FX_NT &&
+                     (a->T & 3) == 0 && (!cv0_sign_bits || (a->T & 31) == 0) && (long)a->n_cond * a->T < (1L << 29) && a->B > 0 && a->B < 65536 &&
+                     a->slope > 0.f && a->slope <= 1.f;
+  const bool al = ((((uintptr_t)a->exc) | ((uintptr_t)a->gb) | ((uintptr_t)a->cv0) | ((uintptr_t)a->k3) | ((uintptr_t)w2_planes)) & 15) == 0 &&
+                  (a->exc_bs & 3) == 0 && (a->gb_bs & 3) == 0 && (!a->cv0 || (a->cv0_bs & 3) == 0);
+  if (g_knob[6] || g_force_tile >= 0 || g_force_generic || !shape || !al)
+    return tdvc_fail(TDVC_EUNSUPPORTED, "film_cond_fwd_x6: outside the fused split-bf16 conditioning forward's contract");
+  CondX6P p = {};
+  p.exc = a->exc; p.exc_bs = a->exc_bs; p.w0 = a->w0; p.w0_rs = a->n_cond * 3; p.w0_off = (a->n_cond - a->n_var) * 3; p.k3 = a->k3;
+  p.wp = (const unsigned short*)w2_planes; p.bias = a->b2; p.cv0 = a->cv0; p.cv0_bs = a->cv0_bs; p.bits = cv0_sign_bits; p.bits_bs = bits_bs;
+  p.y = a->gb; p.y_bs = a->gb_bs; p.T = a->T; p.Cin = a->n_cond; p.Cout = a->C2; p.slope = a->slope;
+  hipStream_t st = (hipStream_t)stream;
+  const int nt = (a->T + FX_NT - 1) / FX_NT;
+  const size_t es_bytes = (size_t)8 * 4 * FX_ESR * sizeof(float);
+  if (x6_mt(a->C2) == 64) {
+    auto k = film_cond_fwd_x6_kernel<4>;
+    TDVC_BIG_LDS_ONCE(k); TDVC_TRACE(k);
+    hipLaunchKernelGGL(k, dim3(nt, a->C2 / 64, a->B), dim3(256), (size_t)(3 * FX_XPL + 3 * 64 * 3 * FX_RS) * 2 + es_bytes, st, p);
+  } else {
+    auto k = film_cond_fwd_x6_kernel<2>;
+    TDVC_BIG_LDS_ONCE(k); TDVC_TRACE(k);
+    hipLaunchKernelGGL(k, dim3(nt, a->C2 / 32, a->B), dim3(256), (size_t)(3 * FX_XPL + 3 * 32 * 3 * FX_RS) * 2 + es_bytes, st, p);
   }
   TDVC_CHECK_LAUNCH();
   return TDVC_OK;

@@ -352,6 +352,38 @@ SIGN_BIT_MASKS = os.environ.get('TDVC_SIGN_BIT_MASKS', '1') == '1'     # cond_va
 FUSED_COND_BWD = os.environ.get('TDVC_FUSED_COND_BWD', '1') == '1'     # cond_var.2 input-grad + cond_var.0 backward in one launch (tdvc_film_cond_bwd)
 
 
+FUSED_COND_FWD_X6 = os.environ.get('TDVC_FUSED_COND_FWD_X6', '1') == '1'      # cond_var.0's window computed inside the split-bf16 cond_var.2 forward
+FUSED_COND_FWD_X6_ALWAYS = False      # tests / tools: also where the two launches measure faster
+
+
+def _film_cond_fwd_x6(ctx, exc, k3, spec_var, spec2):
+    """One launch for the conditioning forward (tdvc_film_cond_fwd_x6): returns gb and leaves cv0 / sign bits on ctx, or None when the
+    shape is outside the kernel's contract (the caller then runs the two launches)."""
+    B, nv, T = exc.shape
+    nc, C2 = spec2.cin, spec2.cout
+    if not (nv == 8 and nc % 4 == 0 and 64 < nc <= 160 and C2 % 32 == 0 and C2 >= X6_FWD_MIN_COUT and T >= 128 and T % 4 == 0 and spec2.k == 3):
+        return None
+    if C2 >= 128 and T >= 2048 and not FUSED_COND_FWD_X6_ALWAYS:
+        # two or more output-channel blocks per tile each recompute the cv0 tile: at long sequences the two launches are faster
+        # (tools/bench_cond_fwd_x6.py: 131 vs 122 us at 136 -> 128, T = 4000; 229 vs 248 / 138 vs 148 / 35 vs 43 us at the other stages)
+        return None
+    lib = L.lib()
+    cv0 = torch.empty((B, nc, T), dtype=torch.float32, device=exc.device)
+    gb = torch.empty((B, C2, T), dtype=torch.float32, device=exc.device)
+    bits = torch.empty((B, nc, T // 32), dtype=torch.int32, device=exc.device) if (SIGN_BIT_MASKS and T % 32 == 0 and T >= 512) else None
+    a = L.FilmCondArgs(B, T, nc, nv, C2, exc.data_ptr(), _bs(exc), spec_var.slot.w, k3.data_ptr(), spec2.slot.w, spec2.slot.b or None,
+                       cv0.data_ptr(), _bs(cv0), gb.data_ptr(), _bs(gb), SLOPE)
+    rc = lib.tdvc_film_cond_fwd_x6(C.byref(a), _weight_planes_x6(spec2, exc.device).data_ptr(), bits.data_ptr() if bits is not None else None,
+                                   _bs(bits) if bits is not None else 0, _stream(exc))
+    if rc == L.EUNSUPPORTED:
+        return None
+    L.check(rc)
+    if RECORDER is not None:
+        RECORDER.append(('film_cond_fwd_x6', B, T, nc, nv, C2, bits is not None))
+    ctx.cv0_tmp, ctx.bits_tmp = cv0, bits
+    return gb
+
+
 class FilmCondFn(Function):
     """gb = cond_var.2(LeakyReLU(cond_var.0([emb; exc]))) (model/generator.py:86-92,103) in one forward launch:
     the time-constant embedding part enters as k3 [B,nc,3], the excitation part of cond_var.0 is an MFMA pre-pass
@@ -370,6 +402,9 @@ class FilmCondFn(Function):
             a = L.FilmCondArgs(B, T, nc, nv, spec2.cout, exc.data_ptr(), _bs(exc), spec_var.slot.w, k3.data_ptr(),
                                spec2.slot.w, spec2.slot.b or None, cv0.data_ptr(), _bs(cv0), gb.data_ptr(), _bs(gb), SLOPE)
             L.check(L.lib().tdvc_film_cond_fwd(C.byref(a), _stream(exc)))
+        elif FUSED_COND_FWD_X6 and X6_FWD and (gb := _film_cond_fwd_x6(ctx, exc, k3, spec_var, spec2)) is not None:
+            cv0, bits = ctx.cv0_tmp, ctx.bits_tmp
+            del ctx.cv0_tmp, ctx.bits_tmp
         else:
             # two launches: the 8-channel excitation window of cond_var.0 (HBM-bound, writes the 136-channel intermediate
             # once) and cond_var.2 on it with LeakyReLU-on-load. Measured faster than the single fused launch at every

@@ -20,7 +20,7 @@ import pytest
 import torch
 
 import test_conv_ops_gpu as OPS
-from common import traced
+from common import rel_l2, traced
 
 pytestmark = pytest.mark.gpu
 TOL = 2e-5
@@ -317,6 +317,96 @@ def test_split_bf16_x6_forward_weight_cache(dev):
         with torch.no_grad():
             ar.params[wkey].div_(1.5)
         ar.materialize()
+
+
+# tdvc_film_cond_fwd_x6 (conv_fwd_x6.hip, film_cond_fwd_x6_kernel): the conditioning forward in ONE launch -- cond_var.0's excitation window
+# computed per tile inside the split-bf16 cond_var.2 forward. Against float64: gb, the stored cv0; the sign bits must equal (stored cv0 > 0)
+# bit for bit (they are packed from the very registers that are stored). Ragged T (not a multiple of the 128-step tile, of 32; the minimum 128),
+# n_cond at both ends of the window, 1..4 output-channel blocks (only the first stores cv0 / bits), edge tiles (3-valued bias at t = 0, T - 1).
+COND_FWD_X6 = [(136, 32, 1024, 3, True), (136, 64, 500, 2, False), (72, 96, 128, 2, True), (160, 256, 640, 2, True), (136, 128, 4000, 4, True)]
+
+
+@pytest.mark.parametrize('nc,C2,T,B,with_bits', COND_FWD_X6, ids=[f'nc{a}_C{b}_T{c}' for a, b, c, _, _ in COND_FWD_X6])
+def test_fused_cond_forward_x6(nc, C2, T, B, with_bits, dev):
+    import ctypes as C
+    P = importlib.import_module('td-vc-gan_amd')
+    ops, arena, L = P.ops, P.arena, P._lib
+    lib = L.lib()
+    torch.manual_seed(nc + C2 + T)
+    nv = 8
+    w0 = torch.randn(nc, nc, 3, dtype=torch.float64) / (nc * 3) ** 0.5
+    w2 = torch.randn(C2, nc, 3, dtype=torch.float64) / (nc * 3) ** 0.5
+    b2 = torch.randn(C2, dtype=torch.float64) * 0.1
+    exc = torch.randn(B, nv, T, dtype=torch.float64)
+    k3 = torch.randn(B, nc, 3, dtype=torch.float64) * 0.3
+    # float64 reference: the 3-valued bias is k3[..., 0] at t = 0, k3[..., 2] at t = T - 1, k3[..., 1] between
+    bias3 = k3[:, :, 1:2].repeat(1, 1, T).clone()
+    bias3[:, :, 0] = k3[:, :, 0]; bias3[:, :, T - 1] = k3[:, :, 2]
+    cv_ref = torch.nn.functional.conv1d(exc, w0[:, nc - nv:, :], padding=1) + bias3
+    gb_ref = torch.nn.functional.conv1d(torch.nn.functional.leaky_relu(cv_ref, 0.2), w2, b2, padding=1)
+    d = lambda t: t.float().to(dev).contiguous()
+    w0d, w2d, b2d, excd, k3d = d(w0), d(w2), d(b2), d(exc), d(k3)
+    spec2 = ops.ConvSpec(nc, C2, 3, 1, 1, 1, 1, False)
+    spec2.slot = arena.ConvSlot(w2d.data_ptr(), b2d.data_ptr(), 0, 0, False, None, 0)
+    planes = ops._weight_planes_x6(spec2, dev)
+    cv0 = torch.full((B, nc, T), float('nan'), device=dev)
+    gb = torch.full((B, C2, T), float('nan'), device=dev)
+    bits = torch.zeros((B, nc, T // 32), dtype=torch.int32, device=dev) if with_bits else None
+    a = L.FilmCondArgs(B, T, nc, nv, C2, excd.data_ptr(), excd.stride(0), w0d.data_ptr(), k3d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(),
+                       cv0.data_ptr(), cv0.stride(0), gb.data_ptr(), gb.stride(0), 0.2)
+    st = torch.cuda.current_stream(dev).cuda_stream
+    lib.tdvc_debug_poison_lds(0xFFFFFFFF, st)
+    with traced() as tr:
+        L.check(lib.tdvc_film_cond_fwd_x6(C.byref(a), planes.data_ptr(), bits.data_ptr() if with_bits else None, bits.stride(0) if with_bits else 0, st))
+        torch.cuda.synchronize()
+    assert any(n.startswith('film_cond_fwd_x6_kernel') for n in tr.names), sorted(tr.names)
+    assert bool(torch.isfinite(gb).all()) and bool(torch.isfinite(cv0).all())
+    e_cv, e_gb = rel_l2(cv0, cv_ref), rel_l2(gb, gb_ref)
+    assert e_cv < TOL and e_gb < TOL, (e_cv, e_gb)
+    if with_bits:
+        want = (cv0 > 0).view(B, nc, T // 32, 32).to(torch.int64)
+        words = (want << torch.arange(32, device=dev, dtype=torch.int64)).sum(-1)
+        got = bits.to(torch.int64) & 0xFFFFFFFF
+        assert torch.equal(got, words), int((got != words).sum())
+
+
+def test_fused_cond_forward_x6_matches_two_launches(dev):
+    """ops.film_cond with the fused forward vs the two-launch forward: same gb and same gradients (dexc, dk3, weight gradients) within fp32
+    rounding -- the backward consumes the fused kernel's cv0 / sign bits."""
+    P = importlib.import_module('td-vc-gan_amd')
+    ops, arena, L = P.ops, P.arena, P._lib
+    torch.manual_seed(77)
+    B, nc, nv, C2, T = 3, 136, 8, 64, 1024
+    w0 = (torch.randn(nc, nc, 3) / (nc * 3) ** 0.5).to(dev)
+    w2 = (torch.randn(C2, nc, 3) / (nc * 3) ** 0.5).to(dev)
+    b2 = (torch.randn(C2) * 0.1).to(dev)
+    w2t = w2.permute(1, 0, 2).contiguous()
+    res = {}
+    for fused in (True, False):
+        dw0, dw2, db2 = torch.zeros_like(w0), torch.zeros_like(w2), torch.zeros_like(b2)
+        sv = ops.ConvSpec(nv, nc, 3, 1, 1, 1, 1, False, w_cin=nc, w_cin_off=nc - nv)
+        sv.slot = arena.ConvSlot(w0.data_ptr(), 0, dw0.data_ptr(), 0, True, None, 0)
+        s2 = ops.ConvSpec(nc, C2, 3, 1, 1, 1, 1, False)
+        s2.slot = arena.ConvSlot(w2.data_ptr(), b2.data_ptr(), dw2.data_ptr(), db2.data_ptr(), True, None, w2t.data_ptr())
+        torch.manual_seed(5)
+        exc = torch.randn(B, nv, T, device=dev, requires_grad=True)
+        k3 = (torch.randn(B, nc, 3, device=dev) * 0.3).requires_grad_(True)
+        cot = torch.randn(B, C2, T, device=dev)
+        old = ops.FUSED_COND_FWD_X6
+        ops.FUSED_COND_FWD_X6 = fused
+        try:
+            with traced() as tr:
+                gb = ops.film_cond(exc, k3, sv, s2)
+                gb.backward(cot)
+                ops.fold_flush(dev)
+                torch.cuda.synchronize()
+        finally:
+            ops.FUSED_COND_FWD_X6 = old
+        assert any(n.startswith('film_cond_fwd_x6_kernel') for n in tr.names) == fused, sorted(tr.names)
+        res[fused] = dict(gb=gb.detach().clone(), dexc=exc.grad.clone(), dk3=k3.grad.clone(), dw0=dw0.clone(), dw2=dw2.clone(), db2=db2.clone())
+    for k in res[True]:
+        e = rel_l2(res[True][k], res[False][k].double().cpu())
+        assert e < 2e-5, (k, e)        # (a LeakyReLU element within rounding of zero may flip between the two cv0 roundings: 1024 x 136 x 3 elements, none expected)
 
 
 # ------------------------------------------------------------------------------------------------ sign-bit masks
