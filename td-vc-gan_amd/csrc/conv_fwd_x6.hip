@@ -239,10 +239,10 @@ struct CondX6P {
   int T, Cin, Cout;                     // Cin = nc
   float slope;
 };
-constexpr int FX_ESR = 36;              // row stride of one phase plane of the excitation tile (34 used)
+constexpr int FX_ES = 140;               // row stride of the excitation tile: window [n0 - 4, n0 + 132) + 4 (rows 16-byte aligned)
 
 template <int CO_TILES>
-__global__ __launch_bounds__(256, 2) void film_cond_fwd_x6_kernel(const CondX6P p) {
+__global__ __launch_bounds__(256, CO_TILES == 2 ? 3 : 2) void film_cond_fwd_x6_kernel(const CondX6P p) {
   extern __shared__ __attribute__((aligned(16))) unsigned short smem16[];
   constexpr int MT = 16 * CO_TILES;
   constexpr int CB = MT / 32;
@@ -252,7 +252,7 @@ __global__ __launch_bounds__(256, 2) void film_cond_fwd_x6_kernel(const CondX6P 
   constexpr int WPT = (WNV + 255) / 256;
   unsigned short* xt = smem16;                        // [3 pieces][4 phases][FX_PR][FX_RS]
   unsigned short* ws = smem16 + 3 * FX_XPL;           // [3 pieces][3 taps][MT][FX_RS]
-  float* es = reinterpret_cast<float*>(ws + 3 * WPL); // [8][4 phases][FX_ESR] excitation window [n0 - 4, n0 + 132), fp32
+  float* es = reinterpret_cast<float*>(ws + 3 * WPL); // [8][FX_ES] excitation window [n0 - 4, n0 + 132), fp32
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wt = wave & 1, wc = wave >> 1;            // x6 product: step half, output-channel half
@@ -272,8 +272,7 @@ __global__ __launch_bounds__(256, 2) void film_cond_fwd_x6_kernel(const CondX6P 
       if (e < 8 * 34) {
         const int row = e / 34, v = e - row * 34, q = n0 - 4 + 4 * v;
         const f32x4 x4 = buf_load4(ers, (q >= 0 && q < T) ? (row * T + q) * 4 : 0x7f000000);
-        es[(row * 4 + 0) * FX_ESR + v] = x4[0]; es[(row * 4 + 1) * FX_ESR + v] = x4[1];
-        es[(row * 4 + 2) * FX_ESR + v] = x4[2]; es[(row * 4 + 3) * FX_ESR + v] = x4[3];
+        *reinterpret_cast<f32x4*>(es + row * FX_ES + 4 * v) = x4;
       }
     }
   }
@@ -304,18 +303,16 @@ __global__ __launch_bounds__(256, 2) void film_cond_fwd_x6_kernel(const CondX6P 
   __syncthreads();                                    // the excitation tile is in LDS
   // B operand of the cv0 product, chunk invariant: lane (column ln, k-lane g) of k-step s holds E'[k = 4s + g][step], k = ce * 3 + j,
   // E'[(ce, j)][t] = exc[ce][t + j - 1]. Column ln of sub-tile n is step n0 + 64 grp + 4 ln + n = window index 64 grp + 4 ln + (n + j + 3)
-  float ef[4][6], eh[6];
+  // (re-read from LDS every chunk: 24 registers less let a third block of the 32-channel variant be resident; the stride-4 lane
+  // pattern is 2..4-way conflicting, 24 dword reads per chunk)
+  int eb[6];
+  float eh[6];
 #pragma unroll
   for (int s = 0; s < 6; ++s) {
     const int k = 4 * s + g, ce = k / 3, j = k - 3 * ce;
-#pragma unroll
-    for (int n = 0; n < 4; ++n) {
-      const int m = n + j + 3;
-      ef[n][s] = es[(ce * 4 + (m & 3)) * FX_ESR + 16 * grp + ln + (m >> 2)];
-    }
+    eb[s] = ce * FX_ES + 64 * grp + 4 * ln + j + 3;
     // halo columns (waves of group 0): column 0 = step n0 - 1 (window index j + 2), column 1 = step n0 + 128 (window index j + 131)
-    const int mh = (ln == 1) ? j + 131 : j + 2;
-    eh[s] = es[(ce * 4 + (mh & 3)) * FX_ESR + (mh >> 2)];
+    eh[s] = es[ce * FX_ES + ((ln == 1) ? j + 131 : j + 2)];
   }
 
   const srd_t w0rs = make_srd(p.w0, (nc - 1) * p.w0_rs * 4 + (p.w0_off + 24) * 4);
@@ -349,7 +346,7 @@ __global__ __launch_bounds__(256, 2) void film_cond_fwd_x6_kernel(const CondX6P 
 #pragma unroll
     for (int s = 0; s < 6; ++s) {
 #pragma unroll
-      for (int n = 0; n < 4; ++n) cv[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[s], ef[n][s], cv[n], 0, 0, 0);
+      for (int n = 0; n < 4; ++n) cv[n] = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[s], es[eb[s] + n], cv[n], 0, 0, 0);
       if (grp == 0) ch4 = __builtin_amdgcn_mfma_f32_16x16x4f32(aw[s], eh[s], ch4, 0, 0, 0);
     }
     const int cbase = c * 32 + 16 * mt + 4 * g;       // channels cbase + r
@@ -541,7 +538,7 @@ extern "C" int tdvc_film_cond_fwd_x6(const tdvc_film_cond_args* a, const void* w
   p.y = a->gb; p.y_bs = a->gb_bs; p.T = a->T; p.Cin = a->n_cond; p.Cout = a->C2; p.slope = a->slope;
   hipStream_t st = (hipStream_t)stream;
   const int nt = (a->T + FX_NT - 1) / FX_NT;
-  const size_t es_bytes = (size_t)8 * 4 * FX_ESR * sizeof(float);
+  const size_t es_bytes = (size_t)8 * FX_ES * sizeof(float);
   if (x6_mt(a->C2) == 64) {
     auto k = film_cond_fwd_x6_kernel<4>;
     TDVC_BIG_LDS_ONCE(k); TDVC_TRACE(k);
