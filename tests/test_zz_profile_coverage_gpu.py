@@ -16,7 +16,7 @@ from common import SESSION_KERNELS, pkg
 pytestmark = pytest.mark.gpu
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 TRACED_FAMILIES = ('conv_lean_kernel', 'conv_wgrad_pipe_kernel', 'conv_wgrad_tile_kernel', 'conv_wgrad_lean_kernel', 'conv_gemm_kernel',
-                   'conv_wgrad_kernel', 'conv_wgrad_x6_kernel', 'conv_fwd_x6_kernel', 'conv_scalar_kernel', 'conv_wgrad_scalar_kernel', 'film_cond0_bwd_kernel', 'film_cond_bwd_kernel', 'film_block_kernel', 'film_block_fwd_kernel',
+                   'conv_wgrad_kernel', 'conv_wgrad_x6_kernel', 'conv_fwd_x6_kernel', 'film_cond_fwd_x6_kernel', 'conv_scalar_kernel', 'conv_wgrad_scalar_kernel', 'film_cond0_bwd_kernel', 'film_cond_bwd_kernel', 'film_block_kernel', 'film_block_fwd_kernel',
                    'wn_gate_kernel', 'small_group_fwd_kernel', 'small_group_dgrad_kernel', 'small_group_wgrad_kernel')
 
 
