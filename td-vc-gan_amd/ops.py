@@ -368,11 +368,12 @@ def _film_cond_fwd_x6(ctx, exc, k3, spec_var, spec2):
         # (tools/bench_cond_fwd_x6.py: 131 vs 122 us at 136 -> 128, T = 4000; 229 vs 248 / 138 vs 148 / 35 vs 43 us at the other stages)
         return None
     lib = L.lib()
-    cv0 = torch.empty((B, nc, T), dtype=torch.float32, device=exc.device)
+    keep = any(ctx.needs_input_grad)      # inference / no_grad: the intermediate is not stored at all
+    cv0 = torch.empty((B, nc, T), dtype=torch.float32, device=exc.device) if keep else None
     gb = torch.empty((B, C2, T), dtype=torch.float32, device=exc.device)
-    bits = torch.empty((B, nc, T // 32), dtype=torch.int32, device=exc.device) if (SIGN_BIT_MASKS and T % 32 == 0 and T >= 512) else None
+    bits = torch.empty((B, nc, T // 32), dtype=torch.int32, device=exc.device) if (keep and SIGN_BIT_MASKS and T % 32 == 0 and T >= 512) else None
     a = L.FilmCondArgs(B, T, nc, nv, C2, exc.data_ptr(), _bs(exc), spec_var.slot.w, k3.data_ptr(), spec2.slot.w, spec2.slot.b or None,
-                       cv0.data_ptr(), _bs(cv0), gb.data_ptr(), _bs(gb), SLOPE)
+                       cv0.data_ptr() if keep else None, _bs(cv0) if keep else 0, gb.data_ptr(), _bs(gb), SLOPE)
     rc = lib.tdvc_film_cond_fwd_x6(C.byref(a), _weight_planes_x6(spec2, exc.device).data_ptr(), bits.data_ptr() if bits is not None else None,
                                    _bs(bits) if bits is not None else 0, _stream(exc))
     if rc == L.EUNSUPPORTED:

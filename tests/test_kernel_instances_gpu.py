@@ -363,6 +363,13 @@ def test_fused_cond_forward_x6(nc, C2, T, B, with_bits, dev):
     assert bool(torch.isfinite(gb).all()) and bool(torch.isfinite(cv0).all())
     e_cv, e_gb = rel_l2(cv0, cv_ref), rel_l2(gb, gb_ref)
     assert e_cv < TOL and e_gb < TOL, (e_cv, e_gb)
+    # inference form: no intermediate, no bits -> the same gb bit for bit
+    gb2 = torch.full((B, C2, T), float('nan'), device=dev)
+    a2 = L.FilmCondArgs(B, T, nc, nv, C2, excd.data_ptr(), excd.stride(0), w0d.data_ptr(), k3d.data_ptr(), w2d.data_ptr(), b2d.data_ptr(),
+                        None, 0, gb2.data_ptr(), gb2.stride(0), 0.2)
+    L.check(lib.tdvc_film_cond_fwd_x6(C.byref(a2), planes.data_ptr(), None, 0, st))
+    torch.cuda.synchronize()
+    assert torch.equal(gb2, gb)
     if with_bits:
         want = (cv0 > 0).view(B, nc, T // 32, 32).to(torch.int64)
         words = (want << torch.arange(32, device=dev, dtype=torch.int64)).sum(-1)
