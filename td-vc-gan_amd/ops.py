@@ -353,7 +353,7 @@ FUSED_COND_BWD = os.environ.get('TDVC_FUSED_COND_BWD', '1') == '1'     # cond_va
 
 
 FUSED_COND_FWD_X6 = os.environ.get('TDVC_FUSED_COND_FWD_X6', '1') == '1'      # cond_var.0's window computed inside the split-bf16 cond_var.2 forward
-FUSED_COND_FWD_X6_ALWAYS = False      # tests / tools: also where the two launches measure faster
+FUSED_COND_FWD_X6_ALWAYS = os.environ.get('TDVC_FUSED_COND_FWD_X6_ALWAYS', '0') == '1'      # tests / tools / A-B: also where the two launches measure faster stand-alone
 
 
 def _film_cond_fwd_x6(ctx, exc, k3, spec_var, spec2):
