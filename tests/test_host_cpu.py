@@ -101,3 +101,21 @@ def test_mel_filterbank_matches_oracle():
                      pad_mode='reflect', return_complex=True)
     Fp = m.basis.shape[0] // 2
     assert float((spec[0, :257] - ref[0].real).abs().max()) < 2e-3 and float((spec[0, Fp:Fp + 257] - ref[0].imag).abs().max()) < 2e-3
+
+
+def test_x6_lds_swizzle_is_conflict_free_under_b128_lane_groups():
+    """The LDS image of the split-bf16 kernels (conv_fwd_x6.hip `swz`, conv_wgrad_x6.hip `x6_swz`): 64-byte rows, 16-byte slot q of row r
+    stored at slot q ^ ((r >> 1) & 3). Under gfx950's ds_read_b128 lane grouping (four NON-contiguous 16-lane groups, MI355X_MICROARCH.md)
+    the MFMA fragment read `row = base + (lane & 15), slot = lane >> 4` must be conflict-free for every base row; the padded 80-byte
+    rows the kernels started with are not (measured: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 0.50, profiles/r03_pmc.txt history)."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location('lds_swizzle_check', os.path.join(ROOT, 'tools', 'lds_swizzle_check.py'))
+    m = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(m)
+    swz = lambda r, q: r * 64 + 16 * (q ^ ((r >> 1) & 3))
+    for base in range(64):
+        assert m.extra_cycles(lambda l, b=base: swz(b + (l & 15), l >> 4)) == 0, base
+    assert m.extra_cycles(lambda l: (l & 15) * 80 + 16 * (l >> 4)) == 4          # one extra cycle in each of the four groups
+    # the swizzle is an involution on the 4 slots of a row: writes and reads use the same formula
+    for r in range(16):
+        assert sorted((q ^ ((r >> 1) & 3)) for q in range(4)) == [0, 1, 2, 3]
