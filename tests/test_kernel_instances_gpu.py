@@ -323,7 +323,8 @@ def test_split_bf16_x6_forward_weight_cache(dev):
 # computed per tile inside the split-bf16 cond_var.2 forward. Against float64: gb, the stored cv0; the sign bits must equal (stored cv0 > 0)
 # bit for bit (they are packed from the very registers that are stored). Ragged T (not a multiple of the 128-step tile, of 32; the minimum 128),
 # n_cond at both ends of the window, 1..4 output-channel blocks (only the first stores cv0 / bits), edge tiles (3-valued bias at t = 0, T - 1).
-COND_FWD_X6 = [(136, 32, 1024, 3, True), (136, 64, 500, 2, False), (72, 96, 128, 2, True), (160, 256, 640, 2, True), (136, 128, 4000, 4, True)]
+COND_FWD_X6 = [(136, 32, 1024, 3, True), (136, 64, 500, 2, False), (72, 96, 128, 2, True), (160, 256, 640, 2, True), (136, 128, 4000, 4, True),
+               (68, 32, 132, 1, False), (144, 64, 260, 1, False), (100, 32, 2048, 1, True)]
 
 
 @pytest.mark.parametrize('nc,C2,T,B,with_bits', COND_FWD_X6, ids=[f'nc{a}_C{b}_T{c}' for a, b, c, _, _ in COND_FWD_X6])
